@@ -1,0 +1,232 @@
+/*
+ * svo.h — C ABI of the MI355X-native sparse-voxel-octree ray traverser.
+ *
+ * This is the drop-in boundary for the ONE hot path of jfjell/Octree-Raymarcher that this
+ * repository rebuilds: the per-pixel SVO march.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference checkout):
+ *
+ *   svo_world_generate   <- World::init / g_pyramid / g_chunk      src/World.cpp:19-43,296-321
+ *                           grow()                                 src/Octree.cpp:74-176
+ *                           BoundsPyramid::init                    src/BoundsPyramid.cpp:47-78
+ *                           Ocroot::build (water plane)            src/Octree.cpp:319-436
+ *   svo_world_create     <- a World whose chunk[] the caller already owns (Ocroot, src/Octree.h:56-76)
+ *   svo_world_upload     <- World::load_gpu + RootAllocator::alloc src/World.cpp:57-94, src/Allocator.cpp:28-35
+ *   svo_world_update     <- World::modify + RootAllocator::subst   src/World.cpp:268-274, src/Allocator.cpp:37-55
+ *   svo_trace            <- World::draw (+ draw_shadowmap)         src/World.cpp:162-266
+ *                           fragment main                          shaders/World.Fragment.glsl:162-203
+ *   svo_trace_rays       <- chunkmarch over a ray list             src/Traverse.cpp:127-171
+ *   svo_world_destroy    <- World::deinit                          src/World.cpp:129-151
+ *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
+ *
+ * Conventions
+ *   - plain C, opaque handle, caller owns every buffer it passes in;
+ *   - every function returns an int status: SVO_OK (0) or a negative svo_status; nothing aborts
+ *     or throws across this boundary (the reference uses assert/die(), src/Util.cpp:72-78);
+ *   - pointers named *_dev are DEVICE pointers (HBM of the device the world was uploaded to),
+ *     all others are host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
+ *     asynchronous on that stream, no host synchronisation happens inside svo_trace*;
+ *   - one handle may be used by one host thread at a time; different handles are independent.
+ *
+ * Semantics are those of the reference's CPU march (src/Traverse.cpp): EPS = 1/8192, step caps
+ * 1000/1000/1000, closed-box containment, restart-from-root descent.  The extra per-hit outputs
+ * (voxel box -> normal, material) follow shaders/Chunkmarch.glsl:128-136,190-295 and
+ * shaders/World.Fragment.glsl:162-178.  There is no CPU fallback in this library: without a
+ * usable HIP device every device entry point returns SVO_ERR_NO_DEVICE.
+ */
+#ifndef SVO_H
+#define SVO_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_ABI_VERSION 1
+
+typedef enum svo_status {
+    SVO_OK                 =  0,
+    SVO_ERR_INVALID_ARG    = -1,
+    SVO_ERR_NO_DEVICE      = -2,   /* no HIP device / HIP call failed; see svo_last_error() */
+    SVO_ERR_OUT_OF_MEMORY  = -3,
+    SVO_ERR_MALFORMED_TREE = -4,   /* node word points outside its pool, cycles, too deep */
+    SVO_ERR_NOT_UPLOADED   = -5,
+    SVO_ERR_UNSUPPORTED    = -6,
+    SVO_ERR_HIP            = -7
+} svo_status;
+
+/* Node word (src/Octree.h:8-26, src/Octree.cpp:38-53): type = value >> 30, offset = value & 0x3FFFFFFF. */
+enum { SVO_EMPTY = 0, SVO_LEAF = 1, SVO_BRANCH = 2, SVO_TWIG = 3 };
+#define SVO_TWIG_LEVELS 2           /* src/Octree.h:30-33 */
+#define SVO_TWIG_SIZE   4
+#define SVO_TWIG_WORDS  64          /* uint16 cells per brick, index z*16 + y*4 + x */
+
+/* One chunk as the caller holds it on the host == the public part of Ocroot (src/Octree.h:56-76).
+ * tree[0] is the root; a BRANCH's 8 children are contiguous, slot = x + 2y + 4z. */
+typedef struct svo_chunk_desc {
+    float           position[3];
+    float           size;
+    uint32_t        depth;          /* leaf voxel edge = size / 2^depth; TWIG nodes sit at level depth-2 */
+    uint32_t        _pad;
+    const uint32_t *tree;
+    uint64_t        trees;
+    const uint16_t *twig;           /* twigs * 64 cells */
+    uint64_t        twigs;
+} svo_chunk_desc;
+
+/* Terrain parameters of World::g_pyramid / g_chunk (src/World.cpp:296-321). */
+typedef struct svo_terrain_params {
+    uint32_t depth;                 /* TREE_MAX_DEPTH, reference 8 */
+    uint32_t pyramid_resolution;    /* PYRAMID_RESOLUTION, reference 256; 0 = 2^depth */
+    float    amplitude;             /* 64 */
+    float    yshift;                /* 16 */
+    int32_t  seed;                  /* integer offset added to the noise x/z shift; reference = 0 */
+    int32_t  water;                 /* !=0: Ocroot::build(y < water_level, water_material) */
+    float    water_level;           /* 6 */
+    uint32_t water_material;        /* 6 */
+    int32_t  threads;               /* host threads for generation; 0 = hardware concurrency */
+    int32_t  _pad;
+} svo_terrain_params;
+
+/* Pinhole camera of the build (the reference rasterises the world box and uses
+ * normalize(hitpoint - eye), shaders/World.Fragment.glsl:165; one ray per pixel here).
+ * dir(px,py) = normalize(forward + right*u + up*v),
+ *   u = (((px+0.5)/width )*2 - 1) * tan_half_x,   v = (1 - ((py+0.5)/height)*2) * tan_half_y,
+ * all in float, no FMA contraction.  The caller supplies the orthonormal basis and the tangents. */
+typedef struct svo_camera {
+    float   eye[3];
+    float   forward[3];
+    float   right[3];
+    float   up[3];
+    float   tan_half_x;
+    float   tan_half_y;
+    int32_t width;                  /* full image size the pixel coordinates refer to */
+    int32_t height;
+} svo_camera;
+
+enum {                              /* svo_trace_params.kernel */
+    SVO_KERNEL_AUTO    = 0,         /* fastest kernel valid for this world */
+    SVO_KERNEL_LITERAL = 1,         /* one thread per ray, restart-from-root, any geometry */
+    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill */
+};
+
+typedef struct svo_trace_params {
+    float    eps;                   /* 0 = 1/8192 (src/Traverse.cpp:8) */
+    int32_t  max_chunk_steps;       /* 0 = 1000   (src/Traverse.cpp:142) */
+    int32_t  max_tree_steps;        /* 0 = 1000   (src/Traverse.cpp:79) */
+    int32_t  max_twig_steps;        /* 0 = 1000   (src/Traverse.cpp:54) */
+    int32_t  shadow;                /* !=0: one shadow ray per primary hit toward -light_dir */
+    float    light_dir[3];          /* directionalLight.direction, default normalize(1,-1,0) (src/Main.cpp:116) */
+    int32_t  kernel;                /* SVO_KERNEL_* */
+    int32_t  _pad;
+    uint32_t *counters_dev;         /* optional [n][4] u32 per ray: node words, brick cells, chunk
+                                       descriptors, tree steps (reference restart-from-root counts);
+                                       only honoured by SVO_KERNEL_LITERAL */
+} svo_trace_params;
+
+/* G-buffer record, 32 bytes per pixel / per ray. */
+enum {
+    SVO_HIT_FLAG      = 1u << 0,    /* primary ray hit a voxel */
+    SVO_SHADOW_TRACED = 1u << 1,    /* a shadow ray was cast from this hit */
+    SVO_SHADOWED      = 1u << 2,    /* ... and it hit something */
+    SVO_ERR_FLAG      = 1u << 15    /* traversal met a malformed node (never on validated worlds) */
+};
+#define SVO_CELL_NONE 0xFFu         /* hit a LEAF node, not a brick cell */
+
+typedef struct svo_hit {
+    float    t;                     /* sigma distance exactly as chunkmarch accumulates it (src/Traverse.cpp:160-161) */
+    float    normal[3];             /* cubeNormal of alpha + beta*(t - EPS) on the hit voxel (shaders/Chunkmarch.glsl:128-136) */
+    uint16_t material;              /* LEAF offset or brick cell value */
+    uint16_t flags;
+    uint32_t chunk;                 /* World::index() linear chunk index */
+    uint32_t node;                  /* index in that chunk's tree[] of the LEAF/TWIG node hit */
+    uint32_t cell;                  /* brick cell word z*16+y*4+x, or SVO_CELL_NONE */
+} svo_hit;
+
+typedef struct svo_world svo_world;
+
+typedef struct svo_world_info {
+    int32_t  width, height, depth, chunksize;
+    int32_t  chunkcoordmin[3];
+    int32_t  uploaded_device;       /* -1 if not uploaded */
+    uint64_t total_trees, total_twigs;
+    uint64_t tree_pool_bytes, twig_pool_bytes, mask_pool_bytes;
+    int32_t  max_chunk_depth;
+    int32_t  exact_geometry;        /* 1: all voxel corners are exact floats -> SVO_KERNEL_STACK allowed */
+} svo_world_info;
+
+/* ---- world construction (host) ------------------------------------------------------------ */
+
+/* World::init(w,h,d,s): generate w*h*d chunks of Simplex terrain.  Chunk (x,y,z) sits at
+ * (chunkcoordmin + (x,y,z)) * chunksize; linear index = World::index(). */
+int svo_world_generate(int w, int h, int d, int chunksize, const int chunkcoordmin[3],
+                       const svo_terrain_params *terrain, svo_world **out);
+
+/* Wrap chunks the caller generated/edited itself.  `chunks` has w*h*d entries in World::index()
+ * order; pools are COPIED.  Node words are validated (SVO_ERR_MALFORMED_TREE). */
+int svo_world_create(const svo_chunk_desc *chunks, int n, int w, int h, int d, int chunksize,
+                     const int chunkcoordmin[3], svo_world **out);
+
+int  svo_world_info_get(const svo_world *, svo_world_info *out);
+/* Borrow the host copy of chunk i (valid until the world is destroyed or chunk i is updated). */
+int  svo_world_chunk(const svo_world *, int i, svo_chunk_desc *out);
+void svo_world_destroy(svo_world *);
+
+/* World::index_float / World::index (src/World.cpp:323-332, 288-293). */
+int  svo_world_index_float(const svo_world *, const float p[3], int q[3]);
+int  svo_world_index(const svo_world *, int x, int y, int z);
+
+/* ---- device residency -------------------------------------------------------------------- */
+
+/* Pack every chunk's tree[] / twig[] into one flat HBM pool each (+ the 64-bit brick occupancy
+ * masks derived from twig[]), build the chunk table, on HIP device `device`. */
+int svo_world_upload(svo_world *, int device);
+
+/* Replace chunk `chunk` by `desc` (edited pools) and refresh HBM: ranges [tree_left,tree_right)
+ * nodes and [twig_left,twig_right) bricks are re-sent in place; realloc!=0 (or growth beyond the
+ * chunk's slot) re-packs the chunk at the pool tail == Ocdelta semantics, src/Octree.h:47-54. */
+int svo_world_update(svo_world *, int chunk, const svo_chunk_desc *desc,
+                     uint64_t tree_left, uint64_t tree_right,
+                     uint64_t twig_left, uint64_t twig_right, int realloc);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+/* Trace the pixel rectangle [x0,x0+w) x [y0,y0+h) of `cam`'s image.  out_dev receives w*h
+ * records, row-major within the rectangle.  Rays launched = w*h (+ one per hit when shadow). */
+int svo_trace(svo_world *, const svo_camera *cam, const svo_trace_params *params,
+              int x0, int y0, int w, int h, svo_hit *out_dev, void *stream);
+
+/* Trace the horizontal bands b = band0 + k*band_stride (k = 0..nbands-1) of the full-width image;
+ * band b covers rows [b*band_height, (b+1)*band_height).  This is the interleaved tile-row
+ * partition used for multi-GPU (rank r of N: band0 = r, band_stride = N, band_height = 8).
+ * out_dev receives nbands*band_height*cam->width records, bands stacked in k order; rows that
+ * fall below the image are written as misses. */
+int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *params,
+                   int band0, int band_stride, int nbands, int band_height,
+                   svo_hit *out_dev, void *stream);
+
+/* chunkmarch over an explicit list: origins_dev/dirs_dev are [n][3] float on the device. */
+int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev, int64_t n,
+                   const svo_trace_params *params, svo_hit *out_dev, void *stream);
+
+/* Number of rays the last svo_trace* call on this world actually marched (primary + shadow);
+ * synchronises `stream` internally — call it outside timed regions. */
+int svo_trace_last_ray_count(svo_world *, void *stream, uint64_t *rays);
+
+/* ---- small device helpers so that C/C++ callers need no HIP headers --------------------- */
+int   svo_device_count(void);
+void *svo_device_alloc(size_t bytes);
+void  svo_device_free(void *p_dev);
+int   svo_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
+int   svo_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
+int   svo_stream_synchronize(void *stream);
+
+const char *svo_last_error(void);   /* thread-local message of the last failing call */
+int         svo_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_H */

@@ -1,0 +1,380 @@
+// device.hip — device half of the C ABI: HBM residency of a world and the trace launches.
+//
+//   svo_world_upload  <- World::load_gpu + RootAllocator::alloc   src/World.cpp:57-94, src/Allocator.cpp:28-35
+//   svo_world_update  <- World::modify + RootAllocator::subst     src/World.cpp:268-274, src/Allocator.cpp:37-55
+//   svo_trace*        <- World::draw / draw_shadowmap             src/World.cpp:162-266
+//
+// The reference's first-fit free-list allocator over GL buffers is not reproduced: a world is
+// packed into one flat pool per kind with per-chunk slots sized by the chunk's host capacity
+// (the reference also sizes GPU slots by capacity, src/Allocator.cpp:30-33), and a chunk that
+// outgrows its slot moves to the pool tail.
+//
+// No CPU fallback: every entry point fails with SVO_ERR_NO_DEVICE / SVO_ERR_HIP when HIP does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "kernel_literal.hip.h"
+#include "kernel_stack.hip.h"
+#include "world.h"
+
+using namespace svo;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+            return (e_ == hipErrorOutOfMemory) ? SVO_ERR_OUT_OF_MEMORY                             \
+                 : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? SVO_ERR_NO_DEVICE     \
+                 : SVO_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+namespace svo {
+
+// bit w of mask[b] = (brick b cell w != 0): one wave per brick, one lane per cell.
+__global__ __launch_bounds__(256) void k_brick_masks(const uint16_t *twig, uint64_t *mask, uint64_t first, uint64_t count)
+{
+    const uint64_t b = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = b < first + count;
+    const uint16_t v = live ? twig[b * TWIG_WORDS + (threadIdx.x & 63)] : (uint16_t)0;
+    const unsigned long long m = __ballot(v != 0);
+    if (live && (threadIdx.x & 63) == 0) mask[b] = m;
+}
+
+static int launch_masks(svo_world &w, uint64_t first, uint64_t count, hipStream_t s)
+{
+    if (!count) return SVO_OK;
+    const uint64_t blocks = (count + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) { set_error("brick pool too large for one mask launch"); return SVO_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_brick_masks, dim3((unsigned)blocks), dim3(256), 0, s, w.d_twig, w.d_mask, first, count);
+    HIP_TRY(hipGetLastError());
+    return SVO_OK;
+}
+
+int release_device(svo_world &w)
+{
+    if (w.device >= 0) {
+        (void)hipSetDevice(w.device);
+        (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
+        (void)hipFree(w.d_mask); (void)hipFree(w.d_work);
+    }
+    w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_work = nullptr;
+    w.device = -1;
+    w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear();
+    w.tree_pool_len = w.twig_pool_len = w.tree_pool_cap = w.twig_pool_cap = 0;
+    return SVO_OK;
+}
+
+template <int MAXLV>
+static void launch_stack(const TraceArgs &A, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_trace_stack<MAXLV, 24>), dim3((unsigned)blocks), dim3(64), 0, s, A);
+}
+
+} // namespace svo
+
+extern "C" {
+
+int svo_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void *svo_device_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error("svo_device_alloc: hipMalloc failed"); return nullptr; }
+    return p;
+}
+void svo_device_free(void *p) { if (p) (void)hipFree(p); }
+int svo_memcpy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return SVO_OK; }
+int svo_memcpy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SVO_OK; }
+int svo_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SVO_OK; }
+
+int svo_world_upload(svo_world *w, int device)
+{
+    if (!w) return SVO_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("svo_world_upload: no HIP device"); return SVO_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { set_error("svo_world_upload: device index out of range"); return SVO_ERR_INVALID_ARG; }
+    for (const ChunkPools &c : w->chunks)
+        if (c.size != (float)w->chunksize) { set_error("svo_world_upload: every chunk's size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
+    release_device(*w);
+    HIP_TRY(hipSetDevice(device));
+    w->device = device;
+
+    // slots: capacity-sized like the reference, 8-node / 1-brick granular
+    const size_t n = w->chunks.size();
+    w->table.assign(n, DevChunk());
+    w->tree_slot.assign(n, 0); w->twig_slot.assign(n, 0);
+    uint64_t tcur = 0, bcur = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ChunkPools &c = w->chunks[i];
+        const uint64_t tcap = std::max<uint64_t>(c.tree_capacity, c.tree.size());
+        const uint64_t bcap = std::max<uint64_t>(c.twig_capacity, c.twig_count());
+        const uint64_t base = ((tcur + 8) & ~(uint64_t)7) - 1;          // base % 8 == 7, base >= tcur
+        DevChunk &e = w->table[i];
+        e.bmin[0] = c.position[0]; e.bmin[1] = c.position[1]; e.bmin[2] = c.position[2];
+        e.levels = c.depth - TWIG_LEVELS;
+        e.tree_off = base;
+        e.twig_off = bcur;
+        w->tree_slot[i] = tcap; w->twig_slot[i] = bcap;
+        tcur = base + tcap;
+        bcur += bcap;
+    }
+    // tail slack so that a chunk that outgrows its slot can be re-packed without a full re-upload
+    w->tree_pool_len = tcur; w->twig_pool_len = bcur;
+    w->tree_pool_cap = tcur + tcur / 4 + 64;
+    w->twig_pool_cap = bcur + bcur / 4 + 16;
+
+    int rc = SVO_OK;
+    do {
+        if (hipMalloc((void **)&w->d_tree, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void **)&w->d_twig, w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
+            hipMalloc((void **)&w->d_mask, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+            hipMalloc((void **)&w->d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
+            hipMalloc((void **)&w->d_work, 2 * sizeof(unsigned long long)) != hipSuccess) {
+            set_error("svo_world_upload: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break;
+        }
+        if (hipMemset(w->d_tree, 0, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
+            hipMemset(w->d_mask, 0, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+            hipMemset(w->d_work, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
+        for (size_t i = 0; i < n && rc == SVO_OK; ++i) {
+            const ChunkPools &c = w->chunks[i];
+            const DevChunk &e = w->table[i];
+            if (hipMemcpy(w->d_tree + e.tree_off, c.tree.data(), c.tree.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) rc = SVO_ERR_HIP;
+            if (rc == SVO_OK && !c.twig.empty() &&
+                hipMemcpy(w->d_twig + e.twig_off * TWIG_WORDS, c.twig.data(), c.twig.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = SVO_ERR_HIP;
+            if (rc == SVO_OK) rc = launch_masks(*w, e.twig_off, c.twig_count(), nullptr);
+        }
+        if (rc != SVO_OK) { if (rc == SVO_ERR_HIP) set_error("svo_world_upload: copy failed"); break; }
+        if (hipMemcpy(w->d_chunks, w->table.data(), n * sizeof(DevChunk), hipMemcpyHostToDevice) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) { set_error("svo_world_upload: chunk table copy failed"); rc = SVO_ERR_HIP; break; }
+    } while (0);
+    if (rc != SVO_OK) { release_device(*w); return rc; }
+    w->occupancy_blocks = 0;
+    return SVO_OK;
+}
+
+int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
+                     uint64_t tree_left, uint64_t tree_right, uint64_t twig_left, uint64_t twig_right, int realloc_)
+{
+    if (!w || !desc || chunk < 0 || chunk >= (int)w->chunks.size() || !desc->tree || !desc->trees) return SVO_ERR_INVALID_ARG;
+    // 1. adopt the edited pools on the host (validated like svo_world_create)
+    ChunkPools next;
+    std::memcpy(next.position, desc->position, sizeof next.position);
+    next.size = desc->size; next.depth = desc->depth;
+    next.tree.assign(desc->tree, desc->tree + desc->trees);
+    if (desc->twigs) next.twig.assign(desc->twig, desc->twig + desc->twigs * TWIG_WORDS);
+    next.tree_capacity = w->chunks[(size_t)chunk].tree_capacity;
+    next.twig_capacity = w->chunks[(size_t)chunk].twig_capacity;
+    while (next.tree_capacity <= next.tree.size() + 8) next.tree_capacity *= 2;
+    while (next.twig_capacity < next.twig_count()) next.twig_capacity *= 2;
+    std::string why;
+    int rc = validate_chunk(next, why);
+    if (rc != SVO_OK) { set_error("svo_world_update: " + why); return rc; }
+    if (next.size != (float)w->chunksize) { set_error("svo_world_update: chunk size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
+    w->chunks[(size_t)chunk].tree.swap(next.tree);
+    w->chunks[(size_t)chunk].twig.swap(next.twig);
+    ChunkPools &c = w->chunks[(size_t)chunk];
+    std::memcpy(c.position, next.position, sizeof c.position);
+    c.size = next.size; c.depth = next.depth;
+    c.tree_capacity = next.tree_capacity; c.twig_capacity = next.twig_capacity;
+    classify_world(*w);
+    if (w->device < 0) return SVO_OK;
+
+    // 2. refresh HBM
+    HIP_TRY(hipSetDevice(w->device));
+    DevChunk &e = w->table[(size_t)chunk];
+    const bool tree_fits = c.tree.size() <= w->tree_slot[(size_t)chunk];
+    const bool twig_fits = c.twig_count() <= w->twig_slot[(size_t)chunk];
+    bool table_dirty = e.levels != c.depth - TWIG_LEVELS || e.bmin[0] != c.position[0] || e.bmin[1] != c.position[1] || e.bmin[2] != c.position[2];
+    e.levels = c.depth - TWIG_LEVELS;
+    e.bmin[0] = c.position[0]; e.bmin[1] = c.position[1]; e.bmin[2] = c.position[2];
+    if (!tree_fits || !twig_fits) {
+        // move the outgrown pool(s) to the tail; no room there -> full re-upload
+        const uint64_t tbase = ((w->tree_pool_len + 8) & ~(uint64_t)7) - 1;
+        const uint64_t need_t = tree_fits ? 0 : c.tree_capacity, need_b = twig_fits ? 0 : c.twig_capacity;
+        if ((!tree_fits && tbase + need_t > w->tree_pool_cap) || (!twig_fits && w->twig_pool_len + need_b > w->twig_pool_cap))
+            return svo_world_upload(w, w->device);
+        if (!tree_fits) { e.tree_off = tbase; w->tree_slot[(size_t)chunk] = need_t; w->tree_pool_len = tbase + need_t; }
+        if (!twig_fits) { e.twig_off = w->twig_pool_len; w->twig_slot[(size_t)chunk] = need_b; w->twig_pool_len += need_b; }
+        table_dirty = true;
+        realloc_ = 1;
+        if (tree_fits) { /* tree stays, only its dirty range is re-sent below */ }
+    }
+    uint64_t tl = tree_left, tr = tree_right, bl = twig_left, br = twig_right;
+    if (realloc_ || !tree_fits) { tl = 0; tr = c.tree.size(); }
+    if (realloc_ || !twig_fits) { bl = 0; br = c.twig_count(); }
+    tr = std::min<uint64_t>(tr, c.tree.size()); br = std::min<uint64_t>(br, c.twig_count());
+    if (tl < tr) HIP_TRY(hipMemcpy(w->d_tree + e.tree_off + tl, c.tree.data() + tl, (tr - tl) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (bl < br) {
+        HIP_TRY(hipMemcpy(w->d_twig + (e.twig_off + bl) * TWIG_WORDS, c.twig.data() + bl * TWIG_WORDS, (br - bl) * TWIG_WORDS * sizeof(uint16_t), hipMemcpyHostToDevice));
+        rc = launch_masks(*w, e.twig_off + bl, br - bl, nullptr);
+        if (rc != SVO_OK) return rc;
+    }
+    if (table_dirty) HIP_TRY(hipMemcpy(w->d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    return SVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
+{
+    if (!w) return SVO_ERR_INVALID_ARG;
+    if (w->device < 0) { set_error("svo_trace: world is not uploaded"); return SVO_ERR_NOT_UPLOADED; }
+    std::memset(&A, 0, sizeof A);
+    // src/Traverse.cpp:129-133
+    const float cs = (float)w->chunksize;
+    const int ics = (int)cs;
+    const int dims[3] = { w->width, w->height, w->depth };
+    for (int a = 0; a < 3; ++a) {
+        A.worldmin[a] = (float)(w->chunkcoordmin[a] * ics);
+        A.worldmax[a] = (float)(w->chunkcoordmin[a] + dims[a]) * cs;
+    }
+    A.chunksize = cs;
+    A.dimw = w->width; A.dimh = w->height; A.dimd = w->depth;
+    A.chunks = w->d_chunks; A.tree = w->d_tree; A.twig = w->d_twig; A.mask = w->d_mask;
+    A.eps = (prm && prm->eps != 0.0f) ? prm->eps : 1.0f / 8192.0f;
+    A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
+    A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;
+    A.cap_twig = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : 1000;
+    A.shadow = (prm && prm->shadow) ? 1 : 0;
+    float l[3] = { 1.0f, -1.0f, 0.0f };                                  // src/Main.cpp:116 (normalised below)
+    if (prm && (prm->light_dir[0] != 0.0f || prm->light_dir[1] != 0.0f || prm->light_dir[2] != 0.0f))
+        std::memcpy(l, prm->light_dir, sizeof l);
+    // shadow direction = normalize(-light_dir), glm::normalize semantics
+    const float nx = -l[0], ny = -l[1], nz = -l[2];
+    const float inv = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
+    A.sdir[0] = nx * inv; A.sdir[1] = ny * inv; A.sdir[2] = nz * inv;
+    A.counters = prm ? prm->counters_dev : nullptr;
+    A.work = w->d_work;
+    return SVO_OK;
+}
+
+static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const TraceArgs &A)
+{
+    const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
+    const bool stack_ok = w->exact_geometry && w->max_levels <= 16;
+    if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
+    if (want == SVO_KERNEL_STACK) {
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry and depth <= 18"); return SVO_ERR_UNSUPPORTED; }
+        return SVO_KERNEL_STACK;
+    }
+    if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }
+    return (stack_ok && !A.counters) ? SVO_KERNEL_STACK : SVO_KERNEL_LITERAL;
+}
+
+static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipStream_t s)
+{
+    const int kernel = pick_kernel(w, prm, A);
+    if (kernel < 0) return kernel;
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipMemsetAsync(w->d_work, 0, 2 * sizeof(unsigned long long), s));
+    if (A.n <= 0) return SVO_OK;
+    if (kernel == SVO_KERNEL_LITERAL) {
+        const int64_t blocks = (A.n + 255) / 256;
+        if (blocks > 0x7FFFFFFF) { set_error("svo_trace: too many rays for one launch"); return SVO_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(k_trace_literal, dim3((unsigned)blocks), dim3(256), 0, s, A);
+    } else {
+        if (w->occupancy_blocks <= 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, w->device));
+            w->occupancy_blocks = prop.multiProcessorCount * 32;       // one wave per block, 32 waves per CU at most
+        }
+        const int blocks = (int)std::min<int64_t>(A.ntiles, w->occupancy_blocks);
+        if (w->max_levels <= 6) launch_stack<6>(A, blocks, s);
+        else if (w->max_levels <= 10) launch_stack<10>(A, blocks, s);
+        else launch_stack<16>(A, blocks, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return SVO_OK;
+}
+
+static int fill_camera(const svo_camera *cam, TraceArgs &A)
+{
+    if (!cam || cam->width <= 0 || cam->height <= 0) { set_error("svo_trace: bad camera"); return SVO_ERR_INVALID_ARG; }
+    A.from_camera = 1;
+    std::memcpy(A.eye, cam->eye, sizeof A.eye); std::memcpy(A.fwd, cam->forward, sizeof A.fwd);
+    std::memcpy(A.right, cam->right, sizeof A.right); std::memcpy(A.up, cam->up, sizeof A.up);
+    A.tanx = cam->tan_half_x; A.tany = cam->tan_half_y;
+    A.imgw = cam->width; A.imgh = cam->height;
+    return SVO_OK;
+}
+
+int svo_trace(svo_world *w, const svo_camera *cam, const svo_trace_params *prm,
+              int x0, int y0, int rw, int rh, svo_hit *out_dev, void *stream)
+{
+    TraceArgs A;
+    int rc = fill_common(w, prm, A);
+    if (rc != SVO_OK) return rc;
+    if ((rc = fill_camera(cam, A)) != SVO_OK) return rc;
+    if (!out_dev || rw < 0 || rh < 0 || x0 < 0 || y0 < 0) { set_error("svo_trace: bad rectangle or output"); return SVO_ERR_INVALID_ARG; }
+    A.x0 = x0; A.y0 = y0; A.w = rw; A.h = rh;
+    A.bh = rh > 0 ? rh : 1; A.ystep = 0;
+    A.n = (int64_t)rw * rh;
+    A.tiles_per_row = (rw + 7) / 8;
+    const int64_t tiles = (int64_t)A.tiles_per_row * ((rh + 7) / 8);
+    if (tiles > 0x3FFFFFFF) { set_error("svo_trace: image too large"); return SVO_ERR_UNSUPPORTED; }
+    A.ntiles = (int32_t)tiles;
+    A.out = out_dev;
+    return launch(w, prm, A, (hipStream_t)stream);
+}
+
+int svo_trace_rows(svo_world *w, const svo_camera *cam, const svo_trace_params *prm,
+                   int band0, int band_stride, int nbands, int band_height, svo_hit *out_dev, void *stream)
+{
+    TraceArgs A;
+    int rc = fill_common(w, prm, A);
+    if (rc != SVO_OK) return rc;
+    if ((rc = fill_camera(cam, A)) != SVO_OK) return rc;
+    if (!out_dev || band0 < 0 || band_stride <= 0 || nbands < 0 || band_height <= 0) { set_error("svo_trace_rows: bad band partition"); return SVO_ERR_INVALID_ARG; }
+    A.x0 = 0; A.y0 = band0 * band_height; A.w = cam->width; A.h = nbands * band_height;
+    A.bh = band_height; A.ystep = band_stride * band_height;
+    A.n = (int64_t)A.w * A.h;
+    A.tiles_per_row = (A.w + 7) / 8;
+    const int64_t tiles = (int64_t)A.tiles_per_row * ((A.h + 7) / 8);
+    if (tiles > 0x3FFFFFFF) { set_error("svo_trace_rows: image too large"); return SVO_ERR_UNSUPPORTED; }
+    A.ntiles = (int32_t)tiles;
+    A.out = out_dev;
+    return launch(w, prm, A, (hipStream_t)stream);
+}
+
+int svo_trace_rays(svo_world *w, const float *origins_dev, const float *dirs_dev, int64_t n,
+                   const svo_trace_params *prm, svo_hit *out_dev, void *stream)
+{
+    TraceArgs A;
+    int rc = fill_common(w, prm, A);
+    if (rc != SVO_OK) return rc;
+    if (n < 0 || (n > 0 && (!origins_dev || !dirs_dev || !out_dev))) { set_error("svo_trace_rays: bad ray list"); return SVO_ERR_INVALID_ARG; }
+    A.from_camera = 0;
+    A.origins = origins_dev; A.dirs = dirs_dev;
+    A.n = n;
+    A.w = 64; A.h = 1; A.bh = 1; A.tiles_per_row = 1;
+    const int64_t tiles = (n + 63) / 64;
+    if (tiles > 0x3FFFFFFF) { set_error("svo_trace_rays: too many rays"); return SVO_ERR_UNSUPPORTED; }
+    A.ntiles = (int32_t)tiles;
+    A.out = out_dev;
+    return launch(w, prm, A, (hipStream_t)stream);
+}
+
+int svo_trace_last_ray_count(svo_world *w, void *stream, uint64_t *rays)
+{
+    if (!w || !rays) return SVO_ERR_INVALID_ARG;
+    if (w->device < 0) return SVO_ERR_NOT_UPLOADED;
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long v[2] = { 0, 0 };
+    HIP_TRY(hipMemcpy(v, w->d_work, sizeof v, hipMemcpyDeviceToHost));
+    *rays = v[1];
+    return SVO_OK;
+}
+
+} // extern "C"

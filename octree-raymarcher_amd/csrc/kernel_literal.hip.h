@@ -1,0 +1,170 @@
+// kernel_literal.hip.h — SVO_KERNEL_LITERAL: one thread per ray, the reference's control flow as
+// it stands (nested chunk / tree / brick loops, descent restarted from the chunk root at every
+// step, float child selection).  Works for any geometry; also produces the reference work
+// counters (node words, brick cells, chunk descriptors, tree steps per ray) that bench.py prices
+// the algorithmic bytes from.  The fast path is kernel_stack.hip.h.
+//
+//   traverse   src/Traverse.cpp:34-48      twigmarch  src/Traverse.cpp:50-72
+//   treemarch  src/Traverse.cpp:74-113     chunkmarch src/Traverse.cpp:127-171
+#pragma once
+#include "march.hip.h"
+
+namespace svo {
+
+struct LitCounters { uint32_t node_words, brick_cells, chunk_descs, tree_steps; };
+
+__device__ inline bool lit_brick(const TraceArgs &A, V3 a, V3 b, V3 g, V3 lo, float size, float voxel,
+                                 const uint16_t *cells, float &s, Voxel &vox, LitCounters &cnt, uint32_t &guard)
+{
+    const V3 hi = lo + size;
+    float t = 0.0f;
+    for (int c = 0; c < A.cap_twig; ++c) {
+        if (++guard > STEP_GUARD) return false;
+        const V3 p = a + b * t;
+        if (!inside(p, lo, hi)) return false;
+        const V3 f = (p - lo) / voxel;
+        const int ox = (int)f.x, oy = (int)f.y, oz = (int)f.z;
+        if (!inside(mk((float)ox, (float)oy, (float)oz), mk(0.0f, 0.0f, 0.0f), mk(3.0f, 3.0f, 3.0f))) return false;
+        const uint32_t word = (uint32_t)(oz * 16 + oy * 4 + ox);
+        cnt.brick_cells++;
+        const V3 vlo = lo + mk((float)ox, (float)oy, (float)oz) * voxel;
+        const uint32_t m = cells[word];
+        if (m != 0) {
+            s = t;
+            vox.lo = vlo; vox.size = voxel; vox.material = m; vox.cell = word;
+            return true;
+        }
+        t += escape(p, g, vlo, vlo + voxel) + A.eps;
+    }
+    return false;
+}
+
+__device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevChunk &ch, float rootsize,
+                                float &s, Voxel &vox, LitCounters &cnt, uint32_t &guard)
+{
+    const uint32_t *tree = A.tree + ch.tree_off;
+    const V3 rlo = ld3(ch.bmin), rhi = rlo + rootsize;
+    float t = 0.0f;
+    for (int i = 0; i < A.cap_tree; ++i) {
+        if (++guard > STEP_GUARD) return false;
+        const V3 p = a + b * t;
+        if (!inside(p, rlo, rhi)) return false;
+        cnt.tree_steps++;
+
+        V3 lo = rlo;
+        float size = rootsize;
+        uint32_t node = 0, word;
+        for (int lv = 0;; ++lv) {
+            cnt.node_words++;
+            word = tree[node];
+            if (node_type(word) != BRANCH || lv >= 32) break;
+            const float half = size * 0.5f;
+            const V3 mid = lo + half;
+            const bool gx = p.x >= mid.x, gy = p.y >= mid.y, gz = p.z >= mid.z;
+            lo = lo + mk(gx ? 1.0f : 0.0f, gy ? 1.0f : 0.0f, gz ? 1.0f : 0.0f) * half;
+            node = node_offset(word) + (uint32_t)gx + 2u * (uint32_t)gy + 4u * (uint32_t)gz;
+            size = half;
+        }
+        const uint32_t type = node_type(word);
+        if (type == LEAF) {
+            s = t - A.eps;
+            vox.lo = lo; vox.size = size; vox.material = node_offset(word) & 0xFFFFu; vox.node = node; vox.cell = SVO_CELL_NONE;
+            return true;
+        }
+        if (type == TWIG) {
+            const float voxel = size / 4.0f;
+            const uint16_t *cells = A.twig + (ch.twig_off + node_offset(word)) * TWIG_WORDS;
+            if (lit_brick(A, p, b, g, lo, size, voxel, cells, s, vox, cnt, guard)) {
+                s += t;
+                vox.node = node;
+                return true;
+            }
+        } else if (type == BRANCH) {
+            return false;                                   // deeper than 32 levels: malformed
+        }
+        t += escape(p, g, lo, lo + size) + A.eps;
+    }
+    return false;
+}
+
+__device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &tout, Voxel &vox, uint32_t &chunk,
+                                 LitCounters &cnt)
+{
+    const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
+    const V3 g = recip(beta);
+    float t = 0.0f;
+    bool hit = true;
+    if (!inside(alpha, wlo, whi)) t = enter(alpha, beta, wlo, whi, hit) + A.eps;
+    if (!hit) return false;
+    uint32_t guard = 0;
+    for (int c = 0; c < A.cap_chunk; ++c) {
+        if (++guard > STEP_GUARD) return false;
+        const V3 p = alpha + beta * t;
+        if (!inside(p, wlo, whi)) return false;
+        const int ci = chunk_index(A, p);
+        cnt.chunk_descs++;
+        const DevChunk ch = A.chunks[ci];
+        const V3 clo = ld3(ch.bmin), chi = clo + A.chunksize;
+        if (!inside(p, clo, chi)) return false;
+        float s = 0.0f;
+        const float rootsize = A.chunksize;             // Ocroot::size == chunksize (checked on create)
+        if (lit_tree(A, p, beta, g, ch, rootsize, s, vox, cnt, guard)) {
+            t += s;
+            tout = t;
+            chunk = (uint32_t)ci;
+            return true;
+        }
+        t += escape(p, g, clo, chi) + A.eps;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_trace_literal(TraceArgs A)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned rays = 0;
+    bool live = k < A.n;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    if (live) {
+        if (A.from_camera) {
+            int px, py;
+            local_to_pixel(A, (int)(k % A.w), (int)(k / A.w), px, py);
+            if (py >= A.imgh || px >= A.imgw) { store_miss(A.out, k, 0); live = false; }
+            else camera_ray(A, px, py, o, d);
+        } else {
+            o = ld3(A.origins + 3 * k);
+            d = ld3(A.dirs + 3 * k);
+        }
+    }
+    if (live) {
+        LitCounters cnt = { 0, 0, 0, 0 };
+        Voxel vox; vox.lo = mk(0, 0, 0); vox.size = 0; vox.material = 0; vox.node = 0; vox.cell = 0;
+        float t = 0.0f;
+        uint32_t chunk = 0;
+        rays = 1;
+        if (lit_world(A, o, d, t, vox, chunk, cnt)) {
+            const V3 point = o + d * (t - A.eps);
+            const V3 n = cube_normal(point, vox.lo, vox.lo + vox.size, A.eps);
+            uint32_t flags = SVO_HIT_FLAG;
+            if (A.shadow) {
+                Voxel sv; float st; uint32_t sc;
+                const bool occluded = lit_world(A, point, ld3(A.sdir), st, sv, sc, cnt);
+                flags |= SVO_SHADOW_TRACED | (occluded ? SVO_SHADOWED : 0u);
+                rays = 2;
+            }
+            store_hit(A.out, k, t, n, vox.material, flags, chunk, vox.node, vox.cell);
+        } else {
+            store_miss(A.out, k, 0);
+        }
+        if (A.counters) {
+            uint4 c; c.x = cnt.node_words; c.y = cnt.brick_cells; c.z = cnt.chunk_descs; c.w = cnt.tree_steps;
+            reinterpret_cast<uint4 *>(A.counters)[k] = c;
+        }
+    }
+    // rays marched: one atomic per wave (all 64 lanes reach this point)
+    unsigned total = rays;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(&A.work[1], (unsigned long long)total);
+}
+
+} // namespace svo

@@ -1,0 +1,68 @@
+// svo_format.h — data formats shared by the host and device halves of libsvo_amd.
+//
+// Host formats are the reference's (src/Octree.h:8-76): 32-bit node words (2-bit type, 30-bit
+// offset), 4x4x4 uint16 bricks, BFS-ordered per-chunk pools.  The DEVICE layout is this build's:
+//
+//   tree pool   one flat uint32 array for all chunks.  Chunk c's node n lives at
+//               tree_pool[tree_off[c] + n] with tree_off[c] % 8 == 7, so that every 8-child block
+//               (node indices 1+8k .. 8+8k, src/Octree.cpp:155-174) is one aligned 32-byte
+//               segment and never straddles a cache line.
+//   twig pool   one flat array of 128-byte bricks (uint16[64], index z*16+y*4+x), 128-B aligned:
+//               one brick == one cache line.
+//   mask pool   one uint64 per brick, bit w set iff brick cell w != 0.  Derived on upload; lets
+//               the brick march test cells from a register and touch the brick line only on a hit.
+//   chunk table 32 bytes per chunk in World::index() order (the reference's GPUChunk is also 32 B,
+//               src/World.h:16-27; its region/offset pairs become 64-bit element offsets here).
+#pragma once
+#include <stdint.h>
+
+namespace svo {
+
+enum : uint32_t { EMPTY = 0, LEAF = 1, BRANCH = 2, TWIG = 3 };
+constexpr uint32_t TWIG_LEVELS = 2, TWIG_SIZE = 4, TWIG_WORDS = 64;
+constexpr uint32_t OFFSET_MASK = 0x3FFFFFFFu;
+
+constexpr uint32_t node_make(uint32_t type, uint32_t offset) { return (type << 30) | (offset & OFFSET_MASK); }
+constexpr uint32_t node_type(uint32_t w) { return w >> 30; }
+constexpr uint32_t node_offset(uint32_t w) { return w & OFFSET_MASK; }
+
+struct DevChunk {               // 32 bytes
+    float    bmin[3];
+    uint32_t levels;            // depth - TWIG_LEVELS: deepest level a node can sit at
+    uint64_t tree_off;          // index of node 0 in the tree pool (uint32 units), % 8 == 7
+    uint64_t twig_off;          // index of brick 0 in the twig pool / mask pool (brick units)
+};
+static_assert(sizeof(DevChunk) == 32, "chunk table entry is 32 bytes");
+
+// Everything a trace kernel needs, passed by value.
+struct TraceArgs {
+    // world (src/Traverse.cpp:129-133: chunkmin/chunkmax of the whole grid)
+    float    worldmin[3], worldmax[3];
+    float    chunksize;
+    int32_t  dimw, dimh, dimd;
+    const DevChunk *chunks;
+    const uint32_t *tree;
+    const uint16_t *twig;
+    const uint64_t *mask;
+    // rays
+    int32_t  from_camera;       // 1: generate from cam; 0: origins/dirs
+    float    eye[3], fwd[3], right[3], up[3];
+    float    tanx, tany, inv_unused0, inv_unused1;
+    int32_t  imgw, imgh;        // full image size (ray generation)
+    int32_t  x0, y0, w, h;      // local rectangle: local (lx,ly) -> px = x0+lx, py = y0 + (ly/bh)*ystep + ly%bh
+    int32_t  bh, ystep;
+    const float *origins, *dirs;
+    int64_t  n;                 // rays in list mode, w*h in camera mode
+    // parameters
+    float    eps;
+    int32_t  cap_chunk, cap_tree, cap_twig;
+    int32_t  shadow;
+    float    sdir[3];           // normalize(-light_dir), computed on the host
+    // outputs
+    void     *out;              // svo_hit[n]
+    uint32_t *counters;         // optional [n][4]
+    unsigned long long *work;   // [0] tile cursor, [1] rays marched
+    int32_t  ntiles, tiles_per_row;
+};
+
+} // namespace svo

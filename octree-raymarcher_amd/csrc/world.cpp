@@ -1,0 +1,215 @@
+// world.cpp — host half of the C ABI: world construction, validation, World::index helpers.
+//
+// Reference surface mirrored (see include/svo.h for the full map):
+//   World::init          src/World.cpp:19-43     -> svo_world_generate
+//   World::index(_float) src/World.cpp:276-293,323-332
+//   Ocroot               src/Octree.h:56-76      -> svo_chunk_desc / ChunkPools
+// The reference aborts on malformed input (assert / die(), src/Util.cpp:72-78); this library
+// validates and returns an error code instead.
+#include "world.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace svo {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+// One forward pass over the node words.  Accepts what grow() and the box edits produce
+// (children blocks always lie after their parent, at indices 1+8k); rejects anything a kernel
+// could run off: out-of-pool offsets, back edges (cycles), branches deeper than depth-2.
+// Blocks no reachable BRANCH points at (orphans left behind by Ocroot::destroy) are ignored.
+int validate_chunk(const ChunkPools &c, std::string &why)
+{
+    const uint64_t n = c.tree.size();
+    if (n == 0) { why = "empty tree pool"; return SVO_ERR_MALFORMED_TREE; }
+    if (c.depth < TWIG_LEVELS || c.depth > 30) { why = "depth out of range [2,30]"; return SVO_ERR_MALFORMED_TREE; }
+    if ((n - 1) % 8 != 0) { why = "tree pool is not 1 + 8k nodes"; return SVO_ERR_MALFORMED_TREE; }
+    if (!(c.size > 0.0f) || !std::isfinite(c.size)) { why = "chunk size must be positive"; return SVO_ERR_MALFORMED_TREE; }
+    const uint32_t maxlevel = c.depth - TWIG_LEVELS;
+    const uint64_t nbricks = c.twig_count();
+    std::vector<int8_t> block_level((n - 1) / 8, (int8_t)-1);
+    for (uint64_t i = 0; i < n; ++i) {
+        int level = 0;
+        if (i > 0) {
+            level = block_level[(i - 1) / 8];
+            if (level < 0) continue;                       // orphan
+        }
+        const uint32_t word = c.tree[i];
+        const uint64_t off = node_offset(word);
+        switch (node_type(word)) {
+        case BRANCH:
+            if ((uint32_t)level >= maxlevel) { why = "BRANCH below level depth-2"; return SVO_ERR_MALFORMED_TREE; }
+            if (off <= i || off + 8 > n || (off - 1) % 8 != 0) { why = "BRANCH offset outside pool or not a forward 8-block"; return SVO_ERR_MALFORMED_TREE; }
+            if (block_level[(off - 1) / 8] >= 0) { why = "child block referenced twice"; return SVO_ERR_MALFORMED_TREE; }
+            block_level[(off - 1) / 8] = (int8_t)(level + 1);
+            break;
+        case TWIG:
+            if (off >= nbricks) { why = "TWIG offset outside brick pool"; return SVO_ERR_MALFORMED_TREE; }
+            break;
+        default:
+            break;
+        }
+    }
+    return SVO_OK;
+}
+
+// True when every corner of every possible node / brick cell of the chunk is an exactly
+// representable float, i.e. the reference's incremental bmin arithmetic (src/Traverse.cpp:39-45)
+// never rounds.  Then integer cell coordinates reproduce its comparisons exactly, which is what
+// the stack kernel relies on.
+bool chunk_is_exact(const ChunkPools &c, int chunksize)
+{
+    if (c.size != (float)chunksize) return false;
+    int e = 0;
+    if (std::frexp(c.size, &e) != 0.5f) return false;             // power-of-two edge
+    const float voxel = std::ldexp(c.size, -(int)c.depth);
+    if (!(voxel > 0.0f) || !std::isnormal(voxel)) return false;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = c.position[a], hi = c.position[a] + c.size;
+        if (!std::isfinite(lo) || !std::isfinite(hi)) return false;
+        const double k = (double)lo / (double)voxel;
+        if (k != std::floor(k)) return false;                      // position on the voxel lattice
+        const double m = std::fmax(std::fabs((double)lo), std::fabs((double)hi)) / (double)voxel;
+        if (m > 16777216.0) return false;                          // 2^24 lattice steps
+    }
+    return true;
+}
+
+void classify_world(svo_world &w)
+{
+    w.exact_geometry = true;
+    w.max_levels = 0;
+    for (const ChunkPools &c : w.chunks) {
+        if (!chunk_is_exact(c, w.chunksize)) w.exact_geometry = false;
+        w.max_levels = std::max(w.max_levels, (int)(c.depth - TWIG_LEVELS));
+    }
+}
+
+static int positive_mod(int n, int m) { return (m + (n % m)) % m; }
+
+} // namespace svo
+
+using namespace svo;
+
+extern "C" {
+
+int svo_abi_version(void) { return SVO_ABI_VERSION; }
+const char *svo_last_error(void) { return g_error.c_str(); }
+
+int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
+                       const svo_terrain_params *tp, svo_world **out)
+{
+    if (!out || !tp || w <= 0 || h <= 0 || d <= 0 || chunksize <= 0) { set_error("svo_world_generate: bad argument"); return SVO_ERR_INVALID_ARG; }
+    if (tp->depth < TWIG_LEVELS || tp->depth > 20) { set_error("svo_world_generate: depth must be in [2,20]"); return SVO_ERR_INVALID_ARG; }
+    const uint32_t res = tp->pyramid_resolution ? tp->pyramid_resolution : (1u << tp->depth);
+    if (res & (res - 1)) { set_error("svo_world_generate: pyramid_resolution must be a power of two"); return SVO_ERR_INVALID_ARG; }
+    try {
+        svo_world *world = new svo_world();
+        world->width = w; world->height = h; world->depth = d; world->chunksize = chunksize;
+        for (int i = 0; i < 3; ++i) world->chunkcoordmin[i] = ccm ? ccm[i] : 0;
+        TerrainParams p;
+        p.depth = tp->depth; p.pyramid_resolution = tp->pyramid_resolution;
+        p.amplitude = tp->amplitude; p.yshift = tp->yshift; p.seed = tp->seed;
+        p.water = tp->water; p.water_level = tp->water_level; p.water_material = tp->water_material;
+        p.threads = tp->threads;
+        generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
+        classify_world(*world);
+        *out = world;
+        return SVO_OK;
+    } catch (const std::bad_alloc &) {
+        set_error("svo_world_generate: out of host memory");
+        return SVO_ERR_OUT_OF_MEMORY;
+    }
+}
+
+int svo_world_create(const svo_chunk_desc *chunks, int n, int w, int h, int d, int chunksize,
+                     const int ccm[3], svo_world **out)
+{
+    if (!out || !chunks || w <= 0 || h <= 0 || d <= 0 || chunksize <= 0 || n != w * h * d) {
+        set_error("svo_world_create: bad argument (n must equal w*h*d)");
+        return SVO_ERR_INVALID_ARG;
+    }
+    try {
+        svo_world *world = new svo_world();
+        world->width = w; world->height = h; world->depth = d; world->chunksize = chunksize;
+        for (int i = 0; i < 3; ++i) world->chunkcoordmin[i] = ccm ? ccm[i] : 0;
+        world->chunks.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const svo_chunk_desc &s = chunks[i];
+            ChunkPools &c = world->chunks[(size_t)i];
+            if (!s.tree || s.trees == 0 || (s.twigs && !s.twig)) { delete world; set_error("svo_world_create: chunk has no pools"); return SVO_ERR_INVALID_ARG; }
+            std::memcpy(c.position, s.position, sizeof c.position);
+            c.size = s.size; c.depth = s.depth;
+            c.tree.assign(s.tree, s.tree + s.trees);
+            c.twig.assign(s.twig, s.twig + s.twigs * TWIG_WORDS);
+            while (c.tree_capacity <= c.tree.size() + 8) c.tree_capacity *= 2;
+            while (c.twig_capacity < c.twig_count()) c.twig_capacity *= 2;
+            std::string why;
+            const int rc = validate_chunk(c, why);
+            if (rc != SVO_OK) { delete world; set_error("svo_world_create: chunk " + std::to_string(i) + ": " + why); return rc; }
+        }
+        classify_world(*world);
+        *out = world;
+        return SVO_OK;
+    } catch (const std::bad_alloc &) {
+        set_error("svo_world_create: out of host memory");
+        return SVO_ERR_OUT_OF_MEMORY;
+    }
+}
+
+int svo_world_info_get(const svo_world *w, svo_world_info *o)
+{
+    if (!w || !o) return SVO_ERR_INVALID_ARG;
+    std::memset(o, 0, sizeof *o);
+    o->width = w->width; o->height = w->height; o->depth = w->depth; o->chunksize = w->chunksize;
+    for (int i = 0; i < 3; ++i) o->chunkcoordmin[i] = w->chunkcoordmin[i];
+    o->uploaded_device = w->device;
+    for (const ChunkPools &c : w->chunks) { o->total_trees += c.tree.size(); o->total_twigs += c.twig_count(); }
+    o->tree_pool_bytes = w->tree_pool_cap * sizeof(uint32_t);
+    o->twig_pool_bytes = w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t);
+    o->mask_pool_bytes = w->twig_pool_cap * sizeof(uint64_t);
+    o->max_chunk_depth = w->max_levels + (int)TWIG_LEVELS;
+    o->exact_geometry = w->exact_geometry ? 1 : 0;
+    return SVO_OK;
+}
+
+int svo_world_chunk(const svo_world *w, int i, svo_chunk_desc *o)
+{
+    if (!w || !o || i < 0 || i >= (int)w->chunks.size()) return SVO_ERR_INVALID_ARG;
+    const ChunkPools &c = w->chunks[(size_t)i];
+    std::memcpy(o->position, c.position, sizeof o->position);
+    o->size = c.size; o->depth = c.depth; o->_pad = 0;
+    o->tree = c.tree.data(); o->trees = c.tree.size();
+    o->twig = c.twig.data(); o->twigs = c.twig_count();
+    return SVO_OK;
+}
+
+void svo_world_destroy(svo_world *w)
+{
+    if (!w) return;
+    release_device(*w);
+    delete w;
+}
+
+int svo_world_index_float(const svo_world *w, const float p[3], int q[3])
+{   // src/World.cpp:323-332
+    if (!w || !p || !q) return SVO_ERR_INVALID_ARG;
+    const float cs = (float)w->chunksize;
+    for (int i = 0; i < 3; ++i) {
+        float f = p[i] / cs;
+        if (f < 0.0f) f -= 1.0f;
+        q[i] = (int)f;
+    }
+    return SVO_OK;
+}
+
+int svo_world_index(const svo_world *w, int x, int y, int z)
+{   // src/World.cpp:288-293
+    if (!w) return SVO_ERR_INVALID_ARG;
+    return positive_mod(y, w->height) * w->width * w->depth + positive_mod(z, w->depth) * w->width + positive_mod(x, w->width);
+}
+
+} // extern "C"

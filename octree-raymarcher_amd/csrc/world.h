@@ -1,0 +1,39 @@
+// world.h — the svo_world handle behind include/svo.h.
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/svo.h"
+#include "svo_format.h"
+#include "terrain.h"
+
+struct svo_world {
+    // World (src/World.h:44-57)
+    int width = 0, height = 0, depth = 0, chunksize = 0;
+    int chunkcoordmin[3] = { 0, 0, 0 };
+    std::vector<svo::ChunkPools> chunks;          // World::index() order
+
+    // geometry class
+    bool exact_geometry = false;                  // every voxel corner is an exact float
+    int  max_levels = 0;                          // max over chunks of depth - TWIG_LEVELS
+
+    // device residency
+    int device = -1;
+    svo::DevChunk *d_chunks = nullptr;
+    uint32_t *d_tree = nullptr;
+    uint16_t *d_twig = nullptr;
+    uint64_t *d_mask = nullptr;
+    unsigned long long *d_work = nullptr;         // [0] tile cursor, [1] rays marched
+    std::vector<svo::DevChunk> table;             // host mirror of d_chunks
+    std::vector<uint64_t> tree_slot, twig_slot;   // capacity of each chunk's slot (nodes / bricks)
+    uint64_t tree_pool_len = 0, twig_pool_len = 0;    // elements in use (incl. alignment padding)
+    uint64_t tree_pool_cap = 0, twig_pool_cap = 0;    // elements allocated
+    int occupancy_blocks = 0;                     // cached persistent-grid size
+};
+
+namespace svo {
+void set_error(const std::string &msg);
+int  validate_chunk(const ChunkPools &c, std::string &why);
+bool chunk_is_exact(const ChunkPools &c, int chunksize);
+void classify_world(svo_world &w);
+int  release_device(svo_world &w);
+} // namespace svo
