@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the SVO march hot path on MI355X (BASELINE.json metric).
+
+A "step" is one frame: every primary ray of a 1920x1080 image marched through the depth-12
+4x1x4-chunk Simplex world (BASELINE.json configs[2]) plus one shadow ray per primary hit, G-buffer
+written to HBM.  World pools are resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+N > 1: the image is partitioned into 8-row bands dealt round-robin to the ranks (rank r traces
+bands r, r+N, ...; every rank holds the whole world), and each frame ends with ONE RCCL gather of
+the per-rank G-buffer bands to rank 0 (total work fixed -> "scaling": "strong").  The gather of
+frame i overlaps the trace of frame i+1 (double-buffered, RCCL's own stream).
+
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (k_trace_stack) against the
+8 TB/s HBM peak using the ALGORITHMIC bytes of the reference algorithm: per ray
+4*node_words + 2*brick_cells + 32*chunk_descriptors (restart-from-root counts, measured for this
+exact frame by the literal kernel's counters) + 32 B G-buffer record per pixel.  `cpu_baseline`
+is the CPU oracle (oracle/, a port of src/Traverse.cpp) timed on this host on the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (grid w,h,d, depth, image w,h, shadow)
+    "c3_1080p_depth12_4x1x4_shadow": (4, 1, 4, 12, 1920, 1080, True),      # BASELINE configs[2] (the metric's config)
+    "c2_1080p_depth10_1chunk": (1, 1, 1, 10, 1920, 1080, False),           # BASELINE configs[1]
+    "c3small_1080p_depth10_4x1x4_shadow": (4, 1, 4, 10, 1920, 1080, True),  # quick rehearsal of c3
+    "c4_2160p_depth12_4x1x4_shadow": (4, 1, 4, 12, 3840, 2160, True),      # BASELINE configs[3]
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BAND = 8                       # rows per band == tile height of the stack kernel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3_1080p_depth12_4x1x4_shadow", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "literal", "stack"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                                   # before the library: one HIP runtime per process
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the SVO march has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    svo = importlib.import_module("octree-raymarcher_amd")
+    gw, gh, gd, depth, iw, ih, shadow = WORKLOADS[args.workload]
+    kernel = {"auto": svo.KERNEL_AUTO, "literal": svo.KERNEL_LITERAL, "stack": svo.KERNEL_STACK}[args.kernel]
+
+    # ---- world: generated on the host (deterministic -> identical on every rank), resident in HBM
+    t0 = time.time()
+    world = svo.World.generate(gw, gh, gd, 128, depth)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    world.upload(local_rank)
+    t_up = time.time() - t0
+    info = world.info
+    cam = svo.default_camera(gw, gd, 128, iw, ih)
+    prm = svo.trace_params(shadow=shadow, kernel=kernel)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    nbands_total = (ih + BAND - 1) // BAND
+    nb = (nbands_total + world_size - 1) // world_size           # bands per rank (last ones may be padding)
+    rec = 32
+    if world_size == 1:
+        bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)]
+
+        def trace(i):
+            world.trace(cam, prm, (0, 0, iw, ih), bufs[0].data_ptr(), stream)
+    else:
+        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(2)] if rank == 0 else [None, None]
+
+        def trace(i):
+            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i & 1].data_ptr(), stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- untimed: ray count of one frame (primary + shadow), all ranks
+    trace(0)
+    rays_local = world.last_ray_count(stream)
+    rays_t = torch.tensor([rays_local], dtype=torch.int64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(rays_t)
+    rays_frame = int(rays_t.item())
+
+    # ---- untimed, rank 0 at N=1: algorithmic bytes of this frame from the reference work counters
+    algo_bytes = None
+    counters_sum = None
+    if world_size == 1:
+        cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
+        tmp = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
+        cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
+        world.trace(cam, cprm, (0, 0, iw, ih), tmp.data_ptr(), stream)
+        torch.cuda.synchronize()
+        csum = cnt.to(torch.int64).sum(dim=0).tolist()
+        counters_sum = dict(node_words=csum[0], brick_cells=csum[1], chunk_descs=csum[2], tree_steps=csum[3])
+        algo_bytes = 4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih
+        # the fast kernel must have produced the same G-buffer as the literal one (cheap self-check, untimed)
+        trace(0)
+        torch.cuda.synchronize()
+        if not torch.equal(tmp, bufs[0]):
+            raise SystemExit("bench.py: stack and literal kernels disagree on the benchmark frame")
+        del tmp, cnt
+
+    # ---- warmup
+    works = [None, None]
+    for i in range(args.warmup):
+        if world_size > 1 and works[i & 1] is not None:
+            works[i & 1].wait()
+        trace(i)
+        if world_size > 1:
+            works[i & 1] = dist.gather(bufs[i & 1], gathered[i & 1] if rank == 0 else None, dst=0, async_op=True)
+    for wk in works:
+        if wk is not None:
+            wk.wait()
+    works = [None, None]
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        if world_size > 1 and works[i & 1] is not None:
+            works[i & 1].wait()                     # the buffer is free again (its gather finished)
+        ev[i][0].record()
+        trace(i)
+        ev[i][1].record()
+        if world_size > 1:
+            works[i & 1] = dist.gather(bufs[i & 1], gathered[i & 1] if rank == 0 else None, dst=0, async_op=True)
+    for wk in works:
+        if wk is not None:
+            wk.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if world_size > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0 and world_size > 1:
+        # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
+        g = torch.stack(gathered[(args.steps - 1) & 1], dim=1)              # [nb, N, 8, W, 32]
+        frame = g.reshape(nb * world_size * BAND, iw, rec)[:ih]
+        assert frame.shape[0] == ih
+
+    result = None
+    if rank == 0:
+        mrays = rays_frame * args.steps / elapsed / 1e6
+        result = {
+            "metric": "Mrays/s (primary+shadow) at 1920x1080, depth-12 SVO",
+            "value": round(mrays, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "image": [iw, ih], "grid": [gw, gh, gd], "depth_per_chunk": depth, "chunksize": 128,
+                "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
+                "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
+                "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
+                "kernel": args.kernel, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
+                "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
+            },
+        }
+        if world_size == 1:
+            achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            result["roofline"] = {
+                "bound": "hbm", "kernel": "k_trace_stack" if args.kernel != "literal" else "k_trace_literal",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "bytes_per_ray": round(algo_bytes / rays_frame, 2),
+                "kernel_ms_avg": round(kernel_ms_avg, 5),
+                "counters": counters_sum,
+            }
+            if not args.no_cpu_baseline:
+                ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
+                n = gw * gh * gd
+                O = ob.OracleWorld.from_chunks([world.chunk(i, copy=False) for i in range(n)], gw, gh, gd, 128)
+                cores = os.cpu_count() or 1
+                if args.cpu_crop:
+                    c = args.cpu_crop
+                    rect = ((iw - c) // 2, (ih - c) // 2, c, c)
+                else:
+                    rect = (0, 0, iw, ih)
+                t0 = time.perf_counter()
+                ref = O.trace_image(cam, rect=rect, params=ob.make_params(shadow=shadow), threads=cores)
+                dt = time.perf_counter() - t0
+                result["cpu_baseline"] = {
+                    "value": round(O.last_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                    "sample": f"{rect[2]}x{rect[3]} pixels of the same frame (rect x0={rect[0]}, y0={rect[1]}), "
+                              f"{O.last_rays} rays incl. shadow, {dt:.2f} s wall on {cores} threads, oracle/svo_oracle.c -O2",
+                }
+                # parity of the timed product output against the oracle on that sample
+                got = bufs[0].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+                same = all(np.array_equal(got[f], ref[f]) for f in ("flags", "material", "chunk", "node", "cell")) and \
+                    np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+                result["cpu_baseline"]["parity_with_gpu"] = bool(same)
+        print(json.dumps(result), flush=True)
+
+    world.destroy()
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -265,11 +265,14 @@ class World:
         _check(lib.svo_world_info_get(self._h, C.byref(wi)), "svo_world_info_get")
         return wi
 
-    def chunk(self, i: int) -> dict:
+    def chunk(self, i: int, copy: bool = True) -> dict:
+        """Host pools of chunk i.  copy=False borrows the library's arrays (valid until destroy/update)."""
         d = ChunkDesc()
         _check(lib.svo_world_chunk(self._h, i, C.byref(d)), "svo_world_chunk")
-        tree = np.ctypeslib.as_array(d.tree, shape=(d.trees,)).copy()
-        twig = np.ctypeslib.as_array(d.twig, shape=(d.twigs * 64,)).copy() if d.twigs else np.zeros(0, np.uint16)
+        tree = np.ctypeslib.as_array(d.tree, shape=(d.trees,))
+        twig = np.ctypeslib.as_array(d.twig, shape=(d.twigs * 64,)) if d.twigs else np.zeros(0, np.uint16)
+        if copy:
+            tree, twig = tree.copy(), twig.copy()
         return {"position": tuple(d.position), "size": d.size, "depth": d.depth, "tree": tree, "twig": twig}
 
     def index_float(self, p) -> tuple:

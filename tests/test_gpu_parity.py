@@ -1,0 +1,178 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the CPU oracle on the same octree.
+
+Bar (BASELINE.json north_star / SURVEY.md App. D): hit flag, chunk, node, brick cell and material
+bit-exact; t within 1e-4*max(1,t) and normal within 1e-6 (helpers.py also requires t bit-equal,
+which is what the kernels are built to deliver).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_gbuffer_equal, chunks_of, random_rays
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["literal", "stack"]
+
+
+def _kid(svo, name):
+    return {"literal": svo.KERNEL_LITERAL, "stack": svo.KERNEL_STACK}[name]
+
+
+@pytest.fixture(scope="module")
+def worlds(svo, oracle):
+    """(name) -> (product world uploaded, oracle world over the SAME arrays, box)."""
+    out = {}
+    specs = {
+        "c1_depth8": dict(w=1, h=1, d=1, depth=8, ccm=(0, 0, 0)),            # BASELINE configs[0] scene
+        "grid_2x1x2_d6": dict(w=2, h=1, d=2, depth=6, ccm=(0, 0, 0)),
+        "grid_neg_2x2x2_d5": dict(w=2, h=2, d=2, depth=5, ccm=(-1, -1, -1)),  # negative coords: index_float off-by-one path
+        "depth2": dict(w=1, h=1, d=1, depth=2, ccm=(0, 0, 0)),               # root is a TWIG / LEAF / EMPTY
+        "depth10": dict(w=1, h=1, d=1, depth=10, ccm=(0, 0, 0)),
+    }
+    for name, s in specs.items():
+        W = svo.World.generate(s["w"], s["h"], s["d"], 128, s["depth"], chunkcoordmin=s["ccm"])
+        n = s["w"] * s["h"] * s["d"]
+        O = oracle.OracleWorld.from_chunks(chunks_of(W, n), s["w"], s["h"], s["d"], 128, s["ccm"])
+        W.upload(0)
+        lo = np.array(s["ccm"], dtype=np.float64) * 128
+        hi = lo + np.array([s["w"], s["h"], s["d"]]) * 128
+        out[name] = (W, O, lo, hi, s)
+    yield out
+    for W, O, *_ in out.values():
+        W.destroy()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["c1_depth8", "grid_2x1x2_d6", "grid_neg_2x2x2_d5", "depth2", "depth10"])
+def test_random_rays(svo, oracle, worlds, name, kernel):
+    W, O, lo, hi, _ = worlds[name]
+    rng = np.random.default_rng(1234)
+    o, d = random_rays(rng, 20000, lo, hi)
+    want = O.trace_rays(o, d, threads=8)
+    got = W.chunkmarch(o, d, kernel=_kid(svo, kernel))
+    assert (want["flags"] & 1).sum() > 1000
+    assert_gbuffer_equal(got, want, f"{name}/{kernel}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_shadow_rays(svo, oracle, worlds, kernel):
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    rng = np.random.default_rng(7)
+    o, d = random_rays(rng, 20000, lo, hi)
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    got = W.chunkmarch(o, d, shadow=True, kernel=_kid(svo, kernel))
+    assert ((want["flags"] & svo.SHADOWED) != 0).sum() > 100
+    assert_gbuffer_equal(got, want, f"shadow/{kernel}")
+    assert W.last_ray_count() == O.last_rays
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_camera_image_c1(svo, oracle, worlds, kernel):
+    """BASELINE configs[0]: 256x256 primary rays, depth-8 single chunk."""
+    W, O, lo, hi, s = worlds["c1_depth8"]
+    cam = svo.default_camera(1, 1, 128, 256, 256)
+    want = O.trace_image(cam, threads=8)
+    got = W.draw(cam, kernel=_kid(svo, kernel))
+    assert (want["flags"] & 1).mean() > 0.1
+    assert_gbuffer_equal(got, want, f"c1/{kernel}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_camera_rect_and_bands(svo, oracle, worlds, kernel):
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 200, 120)       # ragged: not a multiple of the 8x8 tile
+    full = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+    got = W.draw(cam, shadow=True, kernel=_kid(svo, kernel))
+    assert_gbuffer_equal(got, full, f"full/{kernel}")
+    sub = W.draw(cam, rect=(37, 11, 101, 53), shadow=True, kernel=_kid(svo, kernel))
+    assert_gbuffer_equal(sub, full[11:64, 37:138], f"rect/{kernel}")
+    # interleaved bands (the multi-GPU partition): rank 1 of 2, 8-row bands
+    nb = (120 // 8 + 1) // 2
+    buf = svo.DeviceBuffer(nb * 8 * 200 * 32)
+    W.trace_rows(cam, svo.trace_params(shadow=True, kernel=_kid(svo, kernel)), 1, 2, nb, 8, buf.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    bands = buf.to_numpy(svo.HIT_DTYPE, nb * 8 * 200).reshape(nb, 8, 200)
+    for k in range(nb):
+        y0 = (1 + 2 * k) * 8
+        rows = full[y0:y0 + 8]
+        assert_gbuffer_equal(bands[k, :rows.shape[0]], rows, f"band{k}/{kernel}")
+        if rows.shape[0] < 8:
+            assert np.all(bands[k, rows.shape[0]:]["flags"] == 0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_edge_case_rays(svo, oracle, worlds, kernel):
+    """Axis-parallel rays (inf/NaN reciprocals), origins on faces/corners, outside the world, inside solid."""
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    o, d = [], []
+    axes = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    rng = np.random.default_rng(3)
+    for a in axes:
+        for _ in range(300):
+            p = lo + rng.random(3) * (hi - lo)
+            o.append(p); d.append(a)
+        # origin exactly on a world face / corner, and exactly on voxel lattice planes
+        o.append(lo); d.append(a)
+        o.append(hi); d.append(a)
+        o.append((64.0, 32.0, 64.0)); d.append(a)
+        o.append((0.0, 0.0, 0.0)); d.append(a)
+        o.append((128.0, 16.0, 128.0)); d.append(a)          # on the chunk seam
+        o.append((-50.0, 20.0, 60.0)); d.append(a)           # outside, may or may not enter
+        o.append((300.0, 500.0, 60.0)); d.append(a)
+    # deep inside solid terrain, and high in the sky looking down
+    for _ in range(500):
+        o.append((rng.random() * 256, 1.0, rng.random() * 256)); d.append(rng.normal(size=3))
+        o.append((rng.random() * 256, 127.0, rng.random() * 256)); d.append((0.001 * rng.normal(), -1.0, 0.001 * rng.normal()))
+    # zero direction and NaN direction: must terminate as misses
+    o.append((10.0, 100.0, 10.0)); d.append((0.0, 0.0, 0.0))
+    o.append((10.0, 100.0, 10.0)); d.append((np.nan, 1.0, 0.0))
+    o = np.array(o, dtype=np.float32)
+    d = np.array(d, dtype=np.float64)
+    nrm = np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where(nrm > 0, d / np.where(nrm > 0, nrm, 1), d).astype(np.float32)
+    want = O.trace_rays(o, d, threads=8)
+    got = W.chunkmarch(o, d, kernel=_kid(svo, kernel))
+    assert_gbuffer_equal(got, want, f"edge/{kernel}")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_empty_and_tiny_launches(svo, oracle, worlds, kernel):
+    W, O, lo, hi, s = worlds["c1_depth8"]
+    got = W.chunkmarch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), kernel=_kid(svo, kernel))
+    assert got.shape == (0,)
+    o = np.array([[64, 120, 64]], np.float32); d = np.array([[0, -1, 0]], np.float32)
+    assert_gbuffer_equal(W.chunkmarch(o, d, kernel=_kid(svo, kernel)), O.trace_rays(o, d), "single")
+
+
+def test_counters_match_oracle(svo, oracle, worlds):
+    """The literal kernel's reference work counters (used to price algorithmic bytes) equal the oracle's."""
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    rng = np.random.default_rng(11)
+    o, d = random_rays(rng, 5000, lo, hi)
+    want, wc = O.trace_rays(o, d, params=oracle.make_params(shadow=True), counters=True, threads=8)
+    got, gc = W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_LITERAL, counters=True)
+    assert_gbuffer_equal(got, want, "counters")
+    assert np.array_equal(gc, wc)
+
+
+def test_auto_kernel_is_stack_and_literal_agrees(svo, worlds):
+    W, O, lo, hi, s = worlds["depth10"]
+    assert W.info.exact_geometry == 1
+    cam = svo.default_camera(1, 1, 128, 320, 200)
+    a = W.draw(cam, shadow=True, kernel=svo.KERNEL_AUTO)
+    b = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL)
+    assert_gbuffer_equal(a, b, "auto-vs-literal")
+
+
+def test_inexact_geometry_uses_literal(svo, oracle):
+    """Chunk size 100 (not a power of two): voxel corners are not exact floats -> stack kernel refused, literal used."""
+    W0 = svo.World.generate(1, 1, 1, 100, 6)
+    assert W0.info.exact_geometry == 0
+    O = oracle.OracleWorld.from_chunks(chunks_of(W0, 1), 1, 1, 1, 100)
+    W0.upload(0)
+    rng = np.random.default_rng(5)
+    o, d = random_rays(rng, 5000, (0, 0, 0), (100, 100, 100))
+    assert_gbuffer_equal(W0.chunkmarch(o, d), O.trace_rays(o, d, threads=8), "size100")
+    with pytest.raises(svo.SvoError):
+        W0.chunkmarch(o, d, kernel=svo.KERNEL_STACK)
+    W0.destroy()
