@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3_1080p_depth12_4x1x4_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "literal", "stack"])
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight: frame i is issued on HIP stream i %% S into G-buffer i %% S, so the long-ray "
+                         "tail of one frame overlaps the bulk of the next (1 = strictly serialized frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
     args = ap.parse_args()
@@ -84,23 +87,49 @@ def main():
     t_up = time.time() - t0
     info = world.info
     cam = svo.default_camera(gw, gd, 128, iw, ih)
+    if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
+        cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
     prm = svo.trace_params(shadow=shadow, kernel=kernel)
+    S = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
 
     nbands_total = (ih + BAND - 1) // BAND
     nb = (nbands_total + world_size - 1) // world_size           # bands per rank (last ones may be padding)
     rec = 32
     if world_size == 1:
-        bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)]
+        bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
 
         def trace(i):
-            world.trace(cam, prm, (0, 0, iw, ih), bufs[0].data_ptr(), stream)
+            world.trace(cam, prm, (0, 0, iw, ih), bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
     else:
-        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(2)] if rank == 0 else [None, None]
+        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+        gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
 
         def trace(i):
-            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i & 1].data_ptr(), stream)
+            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
+
+    def frame(i, works, events=None):
+        """Issue frame i on its stream: (wait until its G-buffer is free) -> trace -> (RCCL gather to rank 0)."""
+        st = streams[i % S]
+        with torch.cuda.stream(st):
+            if world_size > 1 and works[i % S] is not None:
+                works[i % S].wait()                 # the gather that last read this buffer has finished
+            if events is not None:
+                events[i][0].record(st)
+            trace(i)
+            if events is not None:
+                events[i][1].record(st)
+            if world_size > 1:
+                works[i % S] = dist.gather(bufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain(works):
+        for k, wk in enumerate(works):
+            if wk is not None:
+                with torch.cuda.stream(streams[k]):
+                    wk.wait()
+        for st in streams:
+            st.synchronize()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -110,7 +139,7 @@ def main():
 
     # ---- untimed: ray count of one frame (primary + shadow), all ranks
     trace(0)
-    rays_local = world.last_ray_count(stream)
+    rays_local = world.last_ray_count(streams[0].cuda_stream)
     rays_t = torch.tensor([rays_local], dtype=torch.int64, device=dev)
     if world_size > 1:
         dist.all_reduce(rays_t)
@@ -136,33 +165,19 @@ def main():
         del tmp, cnt
 
     # ---- warmup
-    works = [None, None]
+    works = [None] * S
     for i in range(args.warmup):
-        if world_size > 1 and works[i & 1] is not None:
-            works[i & 1].wait()
-        trace(i)
-        if world_size > 1:
-            works[i & 1] = dist.gather(bufs[i & 1], gathered[i & 1] if rank == 0 else None, dst=0, async_op=True)
-    for wk in works:
-        if wk is not None:
-            wk.wait()
-    works = [None, None]
+        frame(i, works)
+    drain(works)
+    works = [None] * S
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
     t_start = time.perf_counter()
     for i in range(args.steps):
-        if world_size > 1 and works[i & 1] is not None:
-            works[i & 1].wait()                     # the buffer is free again (its gather finished)
-        ev[i][0].record()
-        trace(i)
-        ev[i][1].record()
-        if world_size > 1:
-            works[i & 1] = dist.gather(bufs[i & 1], gathered[i & 1] if rank == 0 else None, dst=0, async_op=True)
-    for wk in works:
-        if wk is not None:
-            wk.wait()
+        frame(i, works, ev)
+    drain(works)
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world_size > 1:
@@ -174,7 +189,7 @@ def main():
 
     if rank == 0 and world_size > 1:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
-        g = torch.stack(gathered[(args.steps - 1) & 1], dim=1)              # [nb, N, 8, W, 32]
+        g = torch.stack(gathered[(args.steps - 1) % S], dim=1)              # [nb, N, 8, W, 32]
         frame = g.reshape(nb * world_size * BAND, iw, rec)[:ih]
         assert frame.shape[0] == ih
 
@@ -200,7 +215,7 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
+                "kernel": args.kernel, "frames_in_flight": S, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }
@@ -242,7 +257,7 @@ def main():
                               f"{O.last_rays} rays incl. shadow, {dt:.2f} s wall on {cores} threads, oracle/svo_oracle.c -O2",
                 }
                 # parity of the timed product output against the oracle on that sample
-                got = bufs[0].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+                got = bufs[(args.steps - 1) % S].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
                 same = all(np.array_equal(got[f], ref[f]) for f in ("flags", "material", "chunk", "node", "cell")) and \
                     np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
                 result["cpu_baseline"]["parity_with_gpu"] = bool(same)

@@ -26,7 +26,9 @@
  *     all others are host pointers;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
  *     asynchronous on that stream, no host synchronisation happens inside svo_trace*;
- *   - one handle may be used by one host thread at a time; different handles are independent.
+ *   - one handle may be used by one host thread at a time; different handles are independent;
+ *   - up to 64 svo_trace* launches of one world may be in flight at once (on different streams:
+ *     frames in flight); each launch owns a private work-cursor slot from a 64-entry ring.
  *
  * Semantics are those of the reference's CPU march (src/Traverse.cpp): EPS = 1/8192, step caps
  * 1000/1000/1000, closed-box containment, restart-from-root descent.  The extra per-hit outputs

@@ -26,7 +26,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvo_amd.so")
+# SVO_AMD_LIB lets kernel A/B experiments point at an alternative build of the same library.
+LIB_PATH = os.environ.get("SVO_AMD_LIB") or os.path.join(_HERE, "libsvo_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -17,6 +17,13 @@
 #include <cstring>
 #include <string>
 
+#ifndef SVO_STACK_REFILL
+#define SVO_STACK_REFILL 8       // retired lanes per wave that trigger a refill (cheap: rays are staged in LDS)
+#endif
+#ifndef SVO_STACK_WAVES
+#define SVO_STACK_WAVES 5        // waves per SIMD the stack kernel is register-budgeted for (natural allocation)
+#endif
+
 #include "kernel_literal.hip.h"
 #include "kernel_stack.hip.h"
 #include "world.h"
@@ -70,10 +77,21 @@ int release_device(svo_world &w)
     return SVO_OK;
 }
 
+// Persistent grid = the waves the kernel can keep resident (occupancy query), never more tiles than exist.
 template <int MAXLV>
-static void launch_stack(const TraceArgs &A, int blocks, hipStream_t s)
+static int launch_stack(svo_world *w, const TraceArgs &A, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_trace_stack<MAXLV, 24>), dim3((unsigned)blocks), dim3(64), 0, s, A);
+    auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES>;
+    if (w->occupancy_blocks <= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, w->device) != hipSuccess) return SVO_ERR_HIP;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+        w->occupancy_blocks = prop.multiProcessorCount * per_cu;
+    }
+    const int blocks = (int)std::min<int64_t>(A.ntiles, w->occupancy_blocks);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
+    return SVO_OK;
 }
 
 } // namespace svo
@@ -140,12 +158,12 @@ int svo_world_upload(svo_world *w, int device)
             hipMalloc((void **)&w->d_twig, w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
             hipMalloc((void **)&w->d_mask, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
             hipMalloc((void **)&w->d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
-            hipMalloc((void **)&w->d_work, 2 * sizeof(unsigned long long)) != hipSuccess) {
+            hipMalloc((void **)&w->d_work, WORK_SLOTS * 2 * sizeof(unsigned long long)) != hipSuccess) {
             set_error("svo_world_upload: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break;
         }
         if (hipMemset(w->d_tree, 0, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
             hipMemset(w->d_mask, 0, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
-            hipMemset(w->d_work, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
+            hipMemset(w->d_work, 0, WORK_SLOTS * 2 * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
         for (size_t i = 0; i < n && rc == SVO_OK; ++i) {
             const ChunkPools &c = w->chunks[i];
             const DevChunk &e = w->table[i];
@@ -240,7 +258,12 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
         A.worldmax[a] = (float)(w->chunkcoordmin[a] + dims[a]) * cs;
     }
     A.chunksize = cs;
+    A.inv_chunksize = 1.0f / cs;
     A.dimw = w->width; A.dimh = w->height; A.dimd = w->depth;
+    for (int a = 0; a < 3; ++a) {
+        A.ccm[a] = w->chunkcoordmin[a];
+        A.cbase[a] = (dims[a] + (w->chunkcoordmin[a] % dims[a])) % dims[a];
+    }
     A.chunks = w->d_chunks; A.tree = w->d_tree; A.twig = w->d_twig; A.mask = w->d_mask;
     A.eps = (prm && prm->eps != 0.0f) ? prm->eps : 1.0f / 8192.0f;
     A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
@@ -255,7 +278,7 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     const float inv = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
     A.sdir[0] = nx * inv; A.sdir[1] = ny * inv; A.sdir[2] = nz * inv;
     A.counters = prm ? prm->counters_dev : nullptr;
-    A.work = w->d_work;
+    A.work = w->d_work;                 // the launch picks its slot
     return SVO_OK;
 }
 
@@ -277,22 +300,23 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
     const int kernel = pick_kernel(w, prm, A);
     if (kernel < 0) return kernel;
     HIP_TRY(hipSetDevice(w->device));
-    HIP_TRY(hipMemsetAsync(w->d_work, 0, 2 * sizeof(unsigned long long), s));
+    // every launch gets its own {tile cursor, ray count} slot so that launches on different streams may overlap
+    w->work_last = w->work_next;
+    w->work_next = (w->work_next + 1) % WORK_SLOTS;
+    A.work = w->d_work + 2 * w->work_last;
+    HIP_TRY(hipMemsetAsync(A.work, 0, 2 * sizeof(unsigned long long), s));
     if (A.n <= 0) return SVO_OK;
     if (kernel == SVO_KERNEL_LITERAL) {
         const int64_t blocks = (A.n + 255) / 256;
         if (blocks > 0x7FFFFFFF) { set_error("svo_trace: too many rays for one launch"); return SVO_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(k_trace_literal, dim3((unsigned)blocks), dim3(256), 0, s, A);
     } else {
-        if (w->occupancy_blocks <= 0) {
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, w->device));
-            w->occupancy_blocks = prop.multiProcessorCount * 32;       // one wave per block, 32 waves per CU at most
-        }
-        const int blocks = (int)std::min<int64_t>(A.ntiles, w->occupancy_blocks);
-        if (w->max_levels <= 6) launch_stack<6>(A, blocks, s);
-        else if (w->max_levels <= 10) launch_stack<10>(A, blocks, s);
-        else launch_stack<16>(A, blocks, s);
+        if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
+        int rc;
+        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, s);
+        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, s);
+        else rc = launch_stack<16>(w, A, s);
+        if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());
     return SVO_OK;
@@ -372,7 +396,7 @@ int svo_trace_last_ray_count(svo_world *w, void *stream, uint64_t *rays)
     HIP_TRY(hipSetDevice(w->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     unsigned long long v[2] = { 0, 0 };
-    HIP_TRY(hipMemcpy(v, w->d_work, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, w->d_work + 2 * w->work_last, sizeof v, hipMemcpyDeviceToHost));
     *rays = v[1];
     return SVO_OK;
 }

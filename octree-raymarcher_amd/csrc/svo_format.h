@@ -47,7 +47,10 @@ struct TraceArgs {
     // rays
     int32_t  from_camera;       // 1: generate from cam; 0: origins/dirs
     float    eye[3], fwd[3], right[3], up[3];
-    float    tanx, tany, inv_unused0, inv_unused1;
+    float    tanx, tany;
+    float    inv_chunksize;     // exact when chunksize is a power of two (stack kernel only)
+    int32_t  ccm[3];            // chunkcoordmin
+    int32_t  cbase[3];          // positive_mod(chunkcoordmin, dims): index of the grid's first chunk per axis
     int32_t  imgw, imgh;        // full image size (ray generation)
     int32_t  x0, y0, w, h;      // local rectangle: local (lx,ly) -> px = x0+lx, py = y0 + (ly/bh)*ystep + ly%bh
     int32_t  bh, ystep;

@@ -1,0 +1,38 @@
+"""Diagnostic (SVO_STACK_TIMING build): per-wave start/end/iterations of one stack-kernel launch."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+svo = importlib.import_module("octree-raymarcher_amd")
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+W = svo.World.generate(4, 1, 4, 128, depth); W.upload(0)
+cam = svo.default_camera(4, 4, 128, 1920, 1080)
+nblk = 256 * 32
+out = svo.DeviceBuffer(1920 * 1080 * 32)
+for rep in range(3):
+    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 8), np.uint32))
+    prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, counters_dev=cnt.ptr)
+    W.trace(cam, prm, (0, 0, 1920, 1080), out.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    c8 = cnt.to_numpy(np.uint32, nblk * 8).reshape(nblk, 8); c = c8[:, :4]; e = c8[:, 4:]
+e = e[c[:, 2] > 0]; c = c[c[:, 2] > 0]
+t0 = c[:, 0].min()
+st = (c[:, 0] - t0).astype(np.int64) * 0.01      # us
+en = (c[:, 1] - t0).astype(np.int64) * 0.01
+print("waves that ran:", len(c), "kernel span %.1f us" % en.max())
+print("start  p50 %.1f p99 %.1f max %.1f" % tuple(np.percentile(st, [50, 99, 100])))
+print("end    p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(en, [10, 50, 90, 99, 100])))
+it = c[:, 2].astype(np.int64)
+print("iters  p50 %d p99 %d max %d   us/iter p50 %.2f" % (np.percentile(it, 50), np.percentile(it, 99), it.max(), np.median((en - st) / it)))
+late = np.argsort(en)[-8:]
+for i in late:
+    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i]))
+for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
+    print("t=%5d us running waves: %d" % (t, ((st <= t) & (en > t)).sum()))
+
+its = it.sum()
+tot_wave_cycles = ((en - st) * 1e-6 * 2.38e9).sum()
+print("wave-iterations total %d; descent section: %.0f cycles per wave-iteration (%.1f%% of wave time at 2.38 GHz)" % (
+    its, e[:, 0].astype(np.float64).sum() * 16 / its, 100.0 * e[:, 0].astype(np.float64).sum() * 16 / tot_wave_cycles))
+print("avg lanes per iteration: tree %.1f twig %.1f world %.1f" % (e[:, 2].astype(np.int64).sum() / its, (e[:, 3] & 0xFFFFF).astype(np.int64).sum() / its, (e[:, 3] >> 20).astype(np.int64).sum() / its))
+print("cycles per wave-iteration overall: %.0f" % (tot_wave_cycles / its))
