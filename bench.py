@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight: frame i is issued on HIP stream i %% S into G-buffer i %% S, so the long-ray "
                          "tail of one frame overlaps the bulk of the next (1 = strictly serialized frames)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured path). gloo = rehearsal of the N>1 control flow on a box with "
+                         "fewer GPUs than ranks: ranks share devices and the gather is staged through host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
     args = ap.parse_args()
@@ -68,11 +71,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the SVO march has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     svo = importlib.import_module("octree-raymarcher_amd")
     gw, gh, gd, depth, iw, ih, shadow = WORKLOADS[args.workload]
@@ -94,8 +102,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
 
-    nbands_total = (ih + BAND - 1) // BAND
-    nb = (nbands_total + world_size - 1) // world_size           # bands per rank (last ones may be padding)
+    nb = svo.partition.bands_per_rank(ih, world_size, BAND)     # bands per rank (last ones may be padding)
     rec = 32
     if world_size == 1:
         bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
@@ -104,7 +111,8 @@ def main():
             world.trace(cam, prm, (0, 0, iw, ih), bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
     else:
         bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
-        gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
+        gdev = dev if args.backend == "nccl" else torch.device("cpu")
+        gathered = [[torch.empty(bufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
 
         def trace(i):
             world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
@@ -121,7 +129,11 @@ def main():
             if events is not None:
                 events[i][1].record(st)
             if world_size > 1:
-                works[i % S] = dist.gather(bufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
+                if args.backend == "nccl":
+                    works[i % S] = dist.gather(bufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
+                else:                               # rehearsal: staged through the host, synchronous
+                    st.synchronize()
+                    dist.gather(bufs[i % S].cpu(), gathered[i % S] if rank == 0 else None, dst=0)
 
     def drain(works):
         for k, wk in enumerate(works):
@@ -140,7 +152,8 @@ def main():
     # ---- untimed: ray count of one frame (primary + shadow), all ranks
     trace(0)
     rays_local = world.last_ray_count(streams[0].cuda_stream)
-    rays_t = torch.tensor([rays_local], dtype=torch.int64, device=dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    rays_t = torch.tensor([rays_local], dtype=torch.int64, device=cdev)
     if world_size > 1:
         dist.all_reduce(rays_t)
     rays_frame = int(rays_t.item())
@@ -181,7 +194,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world_size > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -189,9 +202,14 @@ def main():
 
     if rank == 0 and world_size > 1:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
-        g = torch.stack(gathered[(args.steps - 1) % S], dim=1)              # [nb, N, 8, W, 32]
-        frame = g.reshape(nb * world_size * BAND, iw, rec)[:ih]
-        assert frame.shape[0] == ih
+        frame_full = svo.partition.deinterleave(gathered[(args.steps - 1) % S], ih, BAND)
+        assert frame_full.shape[0] == ih
+        # untimed self-check: the gathered, de-interleaved frame equals a single-GPU trace of the whole image
+        whole = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
+        world.trace(cam, prm, (0, 0, iw, ih), whole.data_ptr(), stream)
+        torch.cuda.synchronize()
+        if not torch.equal(whole.cpu(), frame_full.cpu()):
+            raise SystemExit("bench.py: gathered multi-GPU frame differs from the single-GPU frame")
 
     result = None
     if rank == 0:
@@ -215,7 +233,7 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "frames_in_flight": S, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
+                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }

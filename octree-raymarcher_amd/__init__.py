@@ -25,6 +25,8 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from . import partition  # noqa: F401  (host-side image partition helpers)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SVO_AMD_LIB lets kernel A/B experiments point at an alternative build of the same library.
 LIB_PATH = os.environ.get("SVO_AMD_LIB") or os.path.join(_HERE, "libsvo_amd.so")
