@@ -1,0 +1,27 @@
+// example_world.cpp — the reference's main-loop calls (src/Main.cpp:80-81,222,314-319) against svo::World.
+//   g++ -std=c++17 -I. example_world.cpp -L.. -lsvo_amd -Wl,-rpath,'$ORIGIN/..' -o example_world
+#include <cstdio>
+#include "svo_world.hpp"
+
+int main(int argc, char **argv)
+{
+    const int depth = argc > 1 ? std::atoi(argv[1]) : 8;
+    try {
+        svo::World world;
+        world.init(4, 1, 4, 128, depth);                 // Main.cpp:80   world.init(4, 4, 4, 128) (one y layer holds the terrain)
+        world.load_gpu(0);                               // Main.cpp:81
+        svo::Camera cam({ 256.0f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, { 0.0f, 1.0f, 0.0f }, 60.0f, 640, 360);
+        svo::GBuffer gbuffer;
+        world.draw(cam, gbuffer, /*shadow=*/true);       // Main.cpp:190-222  shadow pass + primary pass
+        svo_stream_synchronize(nullptr);
+        size_t hits = 0, shadowed = 0;
+        for (const svo_hit &h : gbuffer.download()) { hits += h.flags & SVO_HIT_FLAG; shadowed += (h.flags & SVO_SHADOWED) != 0; }
+        svo::vec3 sigma;
+        const bool hit = svo::chunkmarch({ 256.0f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, &world, &sigma);   // Main.cpp:317 computeTarget
+        std::printf("hits %zu shadowed %zu cursor %s (%.3f %.3f %.3f)\n", hits, shadowed, hit ? "hit" : "miss", sigma.x, sigma.y, sigma.z);
+        return hits > 0 ? 0 : 1;
+    } catch (const svo::Error &e) {
+        std::fprintf(stderr, "error %d: %s\n", e.code, e.what());
+        return 2;
+    }
+}
