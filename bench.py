@@ -251,6 +251,9 @@ def main():
                 "bound": "hbm", "kernel": "k_trace_stack" if args.kernel != "literal" else "k_trace_literal",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                # the same bytes over whole-job time: what the overlapped launches deliver together
+                "achieved_throughput": round(algo_bytes * args.steps / elapsed / 1e9, 2),
+                "frac_throughput": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "bytes_per_ray": round(algo_bytes / rays_frame, 2),
                 "kernel_ms_avg": round(kernel_ms_avg, 5),
