@@ -36,14 +36,11 @@ namespace svo {
 
 enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 
-#ifndef SVO_DESC_ROUNDS
-#define SVO_DESC_ROUNDS 0        // >0: at most this many extra node loads per lane per iteration (time-sliced descent)
-#endif
 #ifndef SVO_VOTE_WORLD
-#define SVO_VOTE_WORLD 16        // lanes waiting for a chunk step that make the wave run it
+#define SVO_VOTE_WORLD 12        // lanes waiting for a chunk step that make the wave run it
 #endif
 #ifndef SVO_VOTE_HIT
-#define SVO_VOTE_HIT 16          // primary hits waiting for their G-buffer record
+#define SVO_VOTE_HIT 24          // primary hits waiting for their G-buffer record
 #endif
 #ifndef SVO_VOTE_BUSY
 #define SVO_VOTE_BUSY 24         // fewer marching lanes than this: serve the waiting ones regardless
@@ -93,10 +90,6 @@ __device__ __forceinline__ V3 cube_normal_pow2(V3 s, V3 lo, float size, float ep
     return mk(ix * inv, iy * inv, iz * inv);
 }
 
-#ifndef SVO_CREEP_ROUNDS
-#define SVO_CREEP_ROUNDS 0       // >0: take up to N consecutive same-cell ("creeping") steps inside one iteration; costs ~15% on ordinary frames, halves pathological ones
-#endif
-
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
@@ -105,8 +98,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const int lane = threadIdx.x;
 #ifdef SVO_STACK_TIMING
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0, n_desc_rounds = 0;
-    unsigned long long cyc_desc = 0, cyc_tree = 0, cyc_twig = 0, cyc_world = 0, cyc_hit = 0, cyc_refill = 0;
+    unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
+    unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
 #endif
 
     const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
@@ -126,9 +119,17 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     bool is_shadow = false;
     int outk = 0;
     V3 alpha = mk(0, 0, 0), beta = mk(0, 0, 1), g = mk(0, 0, 0);
-    float tw = 0.0f, tt = 0.0f, tb = 0.0f;
-    int cw = 0, it = 0, ib = 0;
+    float tw = 0.0f;                // chunkmarch's t (src/Traverse.cpp:135)
+    int cw = 0;
     uint32_t guard = 0;
+    // The level being marched (tree: src/Traverse.cpp:74-113, brick: :50-72) as one "frame": p = O + beta*t is
+    // tested against the box [Blo, Blo+Bsize] and located on a lattice of pitch `res` anchored at Blo.
+    // Entering a brick swaps the frame (and parks the tree level's t / counter); leaving swaps it back.
+    V3 O = mk(0, 0, 0), Blo = mk(0, 0, 0);
+    float Bsize = 0.0f, res = 1.0f, t = 0.0f;
+    int cnt = 0;
+    float tt_saved = 0.0f;
+    int it_saved = 0;
     // chunk
     V3 clo = mk(0, 0, 0);
     const uint32_t *tree = A.tree;
@@ -136,12 +137,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     int levels = 0, ci = 0;
     // descent cache: cell coordinates of the last tree step and the level of the node it ended at
     int pux = 0, puy = 0, puz = 0, valid = 0;
-    uint32_t last_word = 0;         // node word the last tree step ended at (valid while `valid_word`)
-    bool valid_word = false;
-    bool descending = false;        // the last tree step stopped part-way down (SVO_DESC_ROUNDS); resume at desc_node
-    uint32_t desc_node = 0;
     // brick
     unsigned long long bmask = 0;
+    uint32_t hitc = SVO_CELL_NONE;  // M_HIT: which brick cell (or none: LEAF)
 
     for (;;) {
         // ==== refill retired lanes =============================================================
@@ -154,6 +152,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 if (t32 >= A.ntiles) { more = false; break; }
                 tile_first = t32 * 64;
                 tile_next = 0;
+#ifdef SVO_STACK_TIMING
+                ++n_tilegen;
+#endif
                 // all 64 lanes generate the tile's rays (src/Traverse.cpp:135-140 included) and park them in LDS
                 {
                     const int id = tile_first + lane;
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     __syncthreads();                        // one wave per block: orders the LDS writes before the reads
                 }
             }
+#ifdef SVO_STACK_TIMING
+            ++n_refill;
+#endif
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0u));
             const int avail = 64 - tile_next;
             if (mode == M_DONE && rank < avail) {
@@ -226,13 +230,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const bool run_world = n_world > 0 && (n_world >= SVO_VOTE_WORLD || n_busy < SVO_VOTE_BUSY);
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
-        // ==== one march step per live lane ==================================================
-        // `adv`: which accumulator receives escape(E_p, g, E_lo, E_hi) + eps at the end of the step
-        //   0 none, 1 tb (brick cell), 2 tt (tree node / brick exit), 3 tw (chunk exit)
-        int adv = 0;
-        V3 E_p = mk(0, 0, 0), E_lo = mk(0, 0, 0);
-        float E_size = 0.0f;
-
         if (mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD) {     // runaway ray: give up, flag it
             if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
             else store_miss(A.out, outk, SVO_ERR_FLAG);
@@ -240,6 +237,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
 
         // ---- chunk step: src/Traverse.cpp:142-156 -------------------------------------------
+#ifdef SVO_STACK_TIMING
+        n_world_runs += run_world; n_hit_runs += run_hit;
+        n_step += __ballot(mode == M_TREE || mode == M_TWIG) != 0;
+#endif
         if (run_world && mode == M_WORLD) {
             bool miss = cw >= A.cap_chunk;
             if (!miss) {
@@ -251,11 +252,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     const DevChunk ch = A.chunks[ci];
                     clo = ld3(ch.bmin);
                     miss = !inside(p, clo, clo + csize);
-                    if (!miss) {
-                        tt = 0.0f; it = 0; valid = 0; valid_word = false; descending = false;
+                    if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
                         tree = A.tree + ch.tree_off;
                         twig_off = (uint32_t)ch.twig_off;
                         levels = (int)ch.levels;
+                        O = p; t = 0.0f; cnt = 0;
+                        Blo = clo; Bsize = csize;
+                        res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
+                        valid = 0;
                         mode = M_TREE;
                     }
                 }
@@ -266,175 +270,112 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
         }
 
+        // ---- one step of the current level: tree (src/Traverse.cpp:79-111) or brick (:54-70) -----
         if (mode == M_TREE || mode == M_TWIG) {
-            const float cell = csize * __uint_as_float((uint32_t)(127 - levels) << 23);    // csize / 2^levels, exact
-            const V3 pw = alpha + beta * tw;            // the chunk march's origin (src/Traverse.cpp:144,158)
-
-            // ---- tree step: src/Traverse.cpp:79-111 ---------------------------------------
-            if (mode == M_TREE) {
-                const float inv_cell = recip_pow2(cell);                                    // power of two, exact
+            const bool twig = mode == M_TWIG;
+            bool leave = cnt >= (twig ? A.cap_twig : A.cap_tree);
+            cnt += leave ? 0 : 1;
+            const V3 p = O + beta * t;
+            leave |= !inside(p, Blo, Blo + Bsize);
+            // lattice coordinates of p inside the box.  Brick: truncation, as the reference (:58).  Tree: the number
+            // of cell boundaries <= p; truncation gives exactly that unless the quotient is integral (p on a lattice
+            // plane, or rounded onto one), which the rare branch below settles with the reference's own comparison.
+            const float inv_res = recip_pow2(res);
+            const float fx = (p.x - Blo.x) * inv_res, fy = (p.y - Blo.y) * inv_res, fz = (p.z - Blo.z) * inv_res;
+            int ux = (int)fx, uy = (int)fy, uz = (int)fz;
+#ifdef SVO_STACK_TIMING
+            n_fix += __ballot(!twig && ((fx == (float)ux) | (fy == (float)uy) | (fz == (float)uz))) != 0;
+#endif
+            if (!twig && ((fx == (float)ux) | (fy == (float)uy) | (fz == (float)uz))) {
                 const int nmax = (1 << levels) - 1;
-                const V3 p = pw + beta * tt;
-                bool leave = false;
-                int ux = pux, uy = puy, uz = puz, lvl = valid;
-                uint32_t node = desc_node, word = last_word;
-                bool same_node = false;
-                if (!descending) {
-                    leave = it >= A.cap_tree;
-                    if (!leave) {
-                        it++;
-                        leave = !inside(p, clo, clo + csize);
-                    }
-                    if (!leave) {
-                        // integer cell coordinates at level `levels`: number of cell boundaries <= p
-                        ux = (int)((p.x - clo.x) * inv_cell); uy = (int)((p.y - clo.y) * inv_cell); uz = (int)((p.z - clo.z) * inv_cell);
-                        ux = ux > nmax ? nmax : ux; uy = uy > nmax ? nmax : uy; uz = uz > nmax ? nmax : uz;
-                        ux -= (clo.x + (float)ux * cell > p.x) ? 1 : 0;
-                        uy -= (clo.y + (float)uy * cell > p.y) ? 1 : 0;
-                        uz -= (clo.z + (float)uz * cell > p.z) ? 1 : 0;
+                ux = ux > nmax ? nmax : ux; uy = uy > nmax ? nmax : uy; uz = uz > nmax ? nmax : uz;
+                ux -= (Blo.x + (float)ux * res > p.x) ? 1 : 0;
+                uy -= (Blo.y + (float)uy * res > p.y) ? 1 : 0;
+                uz -= (Blo.z + (float)uz * res > p.z) ? 1 : 0;
+            }
+            if (twig) leave |= (ux > 3) | (uy > 3) | (uz > 3);      // isInsideCube(off, 0, 3), :59 (off >= 0 always: p >= Blo)
 
-                        // levels whose cached children base is still on the path
-                        const uint32_t diff = (uint32_t)((ux ^ pux) | (uy ^ puy) | (uz ^ puz));
-                        const int common = levels - (diff ? 32 - __clz((int)diff) : 0);
-                        if (valid_word && common >= valid) {
-                            // still inside the node the previous step ended at (a creeping ray): no load at all
-                            same_node = true;
-                        } else {
-                            const int usable = common + 1 < valid ? common + 1 : valid;
-                            node = 0; lvl = 0;
-                            if (usable > 0) {
-                                const int sh = levels - usable;
-                                node = stk[usable - 1][lane] + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
-                                lvl = usable;
-                            }
-                            word = tree[node];
-                        }
+            bool advance = false;
+            int low = 0;                                            // the located cell spans (low+1) lattice steps
+            if (!leave) {
+                if (!twig) {
+                    // descend from the deepest cached level whose coordinate prefix is unchanged
+                    const uint32_t diff = (uint32_t)((ux ^ pux) | (uy ^ puy) | (uz ^ puz));
+                    const int common = levels - (diff ? 32 - __clz((int)diff) : 0);
+                    const int usable = common + 1 < valid ? common + 1 : valid;
+                    uint32_t node = 0;
+                    int lvl = 0;
+                    if (usable > 0) {
+                        const int sh = levels - usable;
+                        node = stk[usable - 1][lane] + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
+                        lvl = usable;
                     }
-                }
-                if (!leave) {
-#ifdef SVO_STACK_TIMING
-                    unsigned long long td0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td0) :: "memory");
-#endif
-                    if (!same_node) {
-                        // descend; at most SVO_DESC_ROUNDS further loads this iteration (0 = until the node is found):
-                        // a lane with a long way down continues next iteration instead of stalling the wave
-                        for (int r = 0; node_type(word) == BRANCH && lvl < levels && (SVO_DESC_ROUNDS == 0 || r < SVO_DESC_ROUNDS); ++r) {
-                            const uint32_t base = node_offset(word);
-                            stk[lvl][lane] = base;
-                            const int sh = levels - 1 - lvl;
-                            node = base + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
-                            ++lvl;
-                            word = tree[node];
-                        }
+                    uint32_t word = tree[node];
+                    while (node_type(word) == BRANCH && lvl < levels) {
+                        const uint32_t base = node_offset(word);
+                        stk[lvl][lane] = base;
+                        const int sh = levels - 1 - lvl;
+                        node = base + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
+                        ++lvl;
+                        word = tree[node];
                     }
-#ifdef SVO_STACK_TIMING
-                    { unsigned long long td1; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(td1) :: "memory"); cyc_desc += td1 - td0; }
-#endif
                     valid = lvl; pux = ux; puy = uy; puz = uz;
-                    last_word = word;
-                    descending = node_type(word) == BRANCH && lvl < levels;
-                    desc_node = node;
-                    valid_word = !descending;
-                    if (!descending) {
-                        const uint32_t type = node_type(word);
-                        if (type == EMPTY) {
-                            const int low = (1 << (levels - lvl)) - 1;
-                            const V3 lo = mk(clo.x + (float)(ux & ~low) * cell, clo.y + (float)(uy & ~low) * cell, clo.z + (float)(uz & ~low) * cell);
-                            const V3 hi = lo + cell * (float)(low + 1);
-                            float e = escape(p, g, lo, hi);
-                            tt += e + eps;
-                            // creeping (pinned on a face: escape ~ 0): take the following steps here while they
-                            // stay in this node — each round is one full reference step (src/Traverse.cpp:79-90)
-                            for (int r = 0; e < eps && r < SVO_CREEP_ROUNDS && it < A.cap_tree && guard < STEP_GUARD; ++r) {
-                                const V3 q = pw + beta * tt;
-                                if (!inside(q, clo, clo + csize)) break;
-                                int vx = (int)((q.x - clo.x) * inv_cell), vy = (int)((q.y - clo.y) * inv_cell), vz = (int)((q.z - clo.z) * inv_cell);
-                                vx = vx > nmax ? nmax : vx; vy = vy > nmax ? nmax : vy; vz = vz > nmax ? nmax : vz;
-                                vx -= (clo.x + (float)vx * cell > q.x) ? 1 : 0;
-                                vy -= (clo.y + (float)vy * cell > q.y) ? 1 : 0;
-                                vz -= (clo.z + (float)vz * cell > q.z) ? 1 : 0;
-                                if ((((vx ^ ux) | (vy ^ uy) | (vz ^ uz)) & ~low) != 0) break;     // left the node
-                                it++; guard++;
-                                e = escape(q, g, lo, hi);
-                                tt += e + eps;
-                            }
-                        } else if (type == LEAF) {
-                            tw = tw + (tt - eps);                               // src/Traverse.cpp:93,160
-                            ib = (int)SVO_CELL_NONE;                            // M_HIT keeps the hit cell in ib
-                            mode = M_HIT;
-                        } else if (type == TWIG) {
-                            if (!same_node) bmask = A.mask[twig_off + node_offset(word)];
-                            tb = 0.0f; ib = 0;
-                            mode = M_TWIG;
-                        } else {                                                // BRANCH at the last level: malformed
-                            if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
-                            else store_miss(A.out, outk, SVO_ERR_FLAG);
-                            mode = M_DONE;
-                        }
+                    low = (1 << (levels - lvl)) - 1;
+                    const uint32_t type = node_type(word);
+                    if (type == EMPTY) {
+                        advance = true;
+                    } else if (type == LEAF) {
+                        tw = tw + (t - eps);                        // src/Traverse.cpp:93,160
+                        hitc = SVO_CELL_NONE;
+                        mode = M_HIT;
+                    } else if (type == TWIG) {                      // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
+                        bmask = A.mask[twig_off + node_offset(word)];
+                        tt_saved = t; it_saved = cnt;
+                        O = p; t = 0.0f; cnt = 0;
+                        Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
+                        Bsize = res * (float)(low + 1);
+                        res = Bsize * 0.25f;                        // leafsize = size / 4, exact
+                        mode = M_TWIG;
+                    } else {                                        // BRANCH at the last level: malformed
+                        if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
+                        else store_miss(A.out, outk, SVO_ERR_FLAG);
+                        mode = M_DONE;
+                    }
+                } else {
+                    const uint32_t w = (uint32_t)(uz * 16 + uy * 4 + ux);
+                    if ((bmask >> w) & 1ull) {
+                        float s = t;                                // src/Traverse.cpp:63
+                        s += tt_saved;                              // :101
+                        tw = tw + s;                                // :160
+                        hitc = w;
+                        mode = M_HIT;
+                    } else {
+                        advance = true;
                     }
                 }
-                if (leave) {                                                    // src/Traverse.cpp:164-168
-                    adv = 3; E_p = pw; E_lo = clo; E_size = csize;
+            }
+
+            // ---- the one escape evaluation of the step: t += escape + EPS.  advance: out of the located cell from p;
+            //      leave: out of the level's own box from its origin (src/Traverse.cpp:104-105 brick, :164-168 chunk)
+            if (advance | leave) {
+                const V3 E_p = leave ? O : p;
+                const V3 E_lo = leave ? Blo : mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
+                const float E_size = leave ? Bsize : res * (float)(low + 1);
+                const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
+                if (!leave) {
+                    t += e;
+                } else if (twig) {                                  // back to the tree level that entered the brick
+                    t = tt_saved + e;
+                    cnt = it_saved;
+                    O = alpha + beta * tw;                          // the chunk march's p (src/Traverse.cpp:144,158)
+                    Blo = clo; Bsize = csize;
+                    res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
+                    mode = M_TREE;
+                } else {                                            // out of the chunk
+                    tw += e;
                     mode = M_WORLD;
                 }
             }
-
-            // ---- brick step: src/Traverse.cpp:54-70 (a lane that just entered a brick steps at once) --
-            if (mode == M_TWIG) {
-                // the brick node's box from the cached cell coordinates (exact), and the brick march's origin
-                const int low = (1 << (levels - valid)) - 1;
-                const V3 nlo = mk(clo.x + (float)(pux & ~low) * cell, clo.y + (float)(puy & ~low) * cell, clo.z + (float)(puz & ~low) * cell);
-                const float nsize = cell * (float)(low + 1);
-                const V3 pt = pw + beta * tt;                                   // src/Traverse.cpp:81,99
-                bool leave = ib >= A.cap_twig;
-                if (!leave) {
-                    ib++;
-                    const V3 p = pt + beta * tb;
-                    leave = !inside(p, nlo, nlo + nsize);
-                    if (!leave) {
-                        const float voxel = nsize * 0.25f;                      // size / 4, exact
-                        const float inv_voxel = recip_pow2(voxel);              // power of two: (p-lo)/voxel == (p-lo)*inv
-                        const int ox = (int)((p.x - nlo.x) * inv_voxel), oy = (int)((p.y - nlo.y) * inv_voxel), oz = (int)((p.z - nlo.z) * inv_voxel);
-                        leave = ((ox | oy | oz) < 0) | (ox > 3) | (oy > 3) | (oz > 3);
-                        if (!leave) {
-                            const uint32_t w = (uint32_t)(oz * 16 + oy * 4 + ox);
-                            if ((bmask >> w) & 1ull) {
-                                float s = tb;                                   // src/Traverse.cpp:63
-                                s += tt;                                        // :101
-                                tw = tw + s;                                    // :160
-                                ib = (int)w;                                    // M_HIT keeps the hit cell in ib
-                                mode = M_HIT;
-                            } else {
-                                const V3 vlo = mk(nlo.x + (float)ox * voxel, nlo.y + (float)oy * voxel, nlo.z + (float)oz * voxel);
-                                const V3 vhi = vlo + voxel;
-                                float e = escape(p, g, vlo, vhi);
-                                tb += e + eps;
-                                // creeping inside one empty cell: each round is one full reference step (src/Traverse.cpp:54-70)
-                                for (int r = 0; e < eps && r < SVO_CREEP_ROUNDS && ib < A.cap_twig && guard < STEP_GUARD; ++r) {
-                                    const V3 q = pt + beta * tb;
-                                    if (!inside(q, nlo, nlo + nsize)) break;
-                                    const int qx = (int)((q.x - nlo.x) * inv_voxel), qy = (int)((q.y - nlo.y) * inv_voxel), qz = (int)((q.z - nlo.z) * inv_voxel);
-                                    if ((qx != ox) | (qy != oy) | (qz != oz)) break;                // left the cell
-                                    ib++; guard++;
-                                    e = escape(q, g, vlo, vhi);
-                                    tb += e + eps;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (leave) {                                                    // src/Traverse.cpp:104-105
-                    adv = 2; E_p = pt; E_lo = nlo; E_size = nsize;
-                    mode = M_TREE;
-                }
-            }
-        }
-
-        // ---- the one escape evaluation of the step: t += escape + EPS ---------------------------
-        if (adv) {
-            const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
-            if (adv == 2) tt += e;
-            else tw += e;
         }
 
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
@@ -444,27 +385,29 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             mode = M_DONE;
         }
         if (run_hit && mode == M_HIT) {
-            const uint32_t hit_cell = (uint32_t)ib;
-            // which voxel: re-derive the node from the descent cache (no state was kept for it)
-            const float cell = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
-            const int low = (1 << (levels - valid)) - 1;
+            // which voxel: the node comes from the descent cache; the frame still describes the level that hit
             const int sh = levels - valid;
             const uint32_t node = valid > 0
                 ? stk[valid - 1][lane] + (uint32_t)(((pux >> sh) & 1) | (((puy >> sh) & 1) << 1) | (((puz >> sh) & 1) << 2))
                 : 0u;
             const uint32_t word = tree[node];
-            V3 vlo = mk(clo.x + (float)(pux & ~low) * cell, clo.y + (float)(puy & ~low) * cell, clo.z + (float)(puz & ~low) * cell);
-            float vsize = cell * (float)(low + 1);
-            uint32_t material = node_offset(word) & 0xFFFFu;
-            if (hit_cell != SVO_CELL_NONE) {
-                vsize = vsize * 0.25f;
-                vlo = mk(vlo.x + (float)(hit_cell & 3u) * vsize, vlo.y + (float)((hit_cell >> 2) & 3u) * vsize, vlo.z + (float)(hit_cell >> 4) * vsize);
-                material = A.twig[((unsigned long long)twig_off + node_offset(word)) * TWIG_WORDS + hit_cell];
+            V3 vlo;
+            float vsize;
+            uint32_t material;
+            if (hitc == SVO_CELL_NONE) {                            // LEAF node: frame = tree level (Blo = clo, res = cell)
+                const int low = (1 << sh) - 1;
+                vlo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
+                vsize = res * (float)(low + 1);
+                material = node_offset(word) & 0xFFFFu;
+            } else {                                                // brick cell: frame = brick (Blo = node box, res = voxel)
+                vlo = mk(Blo.x + (float)(hitc & 3u) * res, Blo.y + (float)((hitc >> 2) & 3u) * res, Blo.z + (float)(hitc >> 4) * res);
+                vsize = res;
+                material = A.twig[((unsigned long long)twig_off + node_offset(word)) * TWIG_WORDS + hitc];
             }
             const V3 point = alpha + beta * (tw - eps);
             const V3 n = cube_normal_pow2(point, vlo, vsize, eps);
             const uint32_t flags = SVO_HIT_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u);
-            store_hit(A.out, outk, tw, n, material, flags, (uint32_t)ci, node, hit_cell);
+            store_hit(A.out, outk, tw, n, material, flags, (uint32_t)ci, node, hitc);
             mode = M_DONE;
             if (A.shadow) {                             // the lane becomes its own shadow ray
                 alpha = point; beta = sdir; g = sg;
@@ -485,7 +428,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
         reinterpret_cast<uint4 *>(A.counters)[2 * blockIdx.x] = c;
-        uint4 e; e.x = (uint32_t)(cyc_desc >> 4); e.y = 0; e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
+        uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
         reinterpret_cast<uint4 *>(A.counters)[2 * blockIdx.x + 1] = e;
     }
 #endif

@@ -16,8 +16,10 @@ int main(int argc, char **argv)
         svo_stream_synchronize(nullptr);
         size_t hits = 0, shadowed = 0;
         for (const svo_hit &h : gbuffer.download()) { hits += h.flags & SVO_HIT_FLAG; shadowed += (h.flags & SVO_SHADOWED) != 0; }
-        svo::vec3 sigma;
-        const bool hit = svo::chunkmarch({ 256.0f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, &world, &sigma);   // Main.cpp:317 computeTarget
+        // Main.cpp:317 computeTarget.  (From exactly x = 256 this direction lies in a voxel-lattice plane: the
+        // reference's 0 * inf = NaN makes that ray a miss, SURVEY.md App. C — so the cursor starts a little off it.)
+        svo::vec3 sigma = { 0.0f, 0.0f, 0.0f };
+        const bool hit = svo::chunkmarch({ 250.3f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, &world, &sigma);
         std::printf("hits %zu shadowed %zu cursor %s (%.3f %.3f %.3f)\n", hits, shadowed, hit ? "hit" : "miss", sigma.x, sigma.y, sigma.z);
         return hits > 0 ? 0 : 1;
     } catch (const svo::Error &e) {

@@ -32,7 +32,9 @@ for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
 
 its = it.sum()
 tot_wave_cycles = ((en - st) * 1e-6 * 2.38e9).sum()
-print("wave-iterations total %d; descent section: %.0f cycles per wave-iteration (%.1f%% of wave time at 2.38 GHz)" % (
-    its, e[:, 0].astype(np.float64).sum() * 16 / its, 100.0 * e[:, 0].astype(np.float64).sum() * 16 / tot_wave_cycles))
+ex = e[:, 0].astype(np.int64); ey = e[:, 1].astype(np.int64)
+print("wave-iterations total %d" % its)
+print("block runs per iteration: world %.3f hit %.3f refill-rounds %.3f tilegen %.4f integral-fix %.3f" % (
+    (ex & 0xFFFF).sum() / its, (ex >> 16).sum() / its, (ey & 0xFFF).sum() / its, ((ey >> 12) & 0xFF).sum() / its, (ey >> 20).sum() / its))
 print("avg lanes per iteration: tree %.1f twig %.1f world %.1f" % (e[:, 2].astype(np.int64).sum() / its, (e[:, 3] & 0xFFFFF).astype(np.int64).sum() / its, (e[:, 3] >> 20).astype(np.int64).sum() / its))
 print("cycles per wave-iteration overall: %.0f" % (tot_wave_cycles / its))
