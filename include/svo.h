@@ -89,7 +89,13 @@ typedef struct svo_terrain_params {
     float    water_level;           /* 6 */
     uint32_t water_material;        /* 6 */
     int32_t  threads;               /* host threads for generation; 0 = hardware concurrency */
-    int32_t  _pad;
+    /* Sparse refinement (a build extension for deep trees, BASELINE configs[4]; 0 = off = the reference):
+     * a node at level coarse_depth-2 whose box does not touch [refine_min, refine_max] (world units,
+     * closed) becomes a brick sampled at level coarse_depth by the rule of src/Octree.cpp:120-154 instead
+     * of being subdivided down to depth-2.  Full depth only inside the refine box. */
+    uint32_t coarse_depth;
+    float    refine_min[3];
+    float    refine_max[3];
 } svo_terrain_params;
 
 /* Pinhole camera of the build (the reference rasterises the world box and uses

@@ -148,8 +148,10 @@ void ChunkPools::reserve_tree(uint64_t need)
     if (tree.capacity() < tree_capacity) tree.reserve(tree_capacity);
 }
 
-void grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t depth, const HeightPyramid &pyr)
+void grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t depth, const HeightPyramid &pyr,
+                const TerrainParams *sparse)
 {   // src/Octree.cpp:74-176, level-synchronous
+    const bool coarse = sparse && sparse->coarse_depth >= TWIG_LEVELS && sparse->coarse_depth < depth;
     c.position[0] = position[0]; c.position[1] = position[1]; c.position[2] = position[2];
     c.size = size;
     c.depth = depth;
@@ -174,7 +176,11 @@ void grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t dep
                 c.tree[e.slot] = node_make(EMPTY, 0);
             } else if (low > e.y + edge) {
                 c.tree[e.slot] = node_make(LEAF, height_material(py));
-            } else if (level == depth - TWIG_LEVELS) {
+            } else if (level == depth - TWIG_LEVELS ||
+                       (coarse && level == sparse->coarse_depth - TWIG_LEVELS &&
+                        !(e.x + edge >= sparse->refine_min[0] && e.y + edge >= sparse->refine_min[1] && e.z + edge >= sparse->refine_min[2] &&
+                          sparse->refine_max[0] >= e.x && sparse->refine_max[1] >= e.y && sparse->refine_max[2] >= e.z))) {
+                // a brick: at depth-2 (the reference), or earlier outside the refine box (sparse extension)
                 const float voxel = edge / (float)(1 << TWIG_LEVELS);
                 const uint16_t mat = height_material(py);
                 const size_t at = c.twig.size();
@@ -326,7 +332,7 @@ int generate_world(int w, int h, int d, int chunksize, const int ccm[3], const T
                 const int idx = positive_mod(cy, h) * w * d + positive_mod(cz, d) * w + positive_mod(cx, w);
                 ChunkPools &c = chunks[(size_t)idx];
                 const float pos[3] = { (float)cx * (float)chunksize, (float)cy * (float)chunksize, (float)cz * (float)chunksize };
-                grow_chunk(c, pos, (float)chunksize, tp.depth, pyr);
+                grow_chunk(c, pos, (float)chunksize, tp.depth, pyr, &tp);
                 if (tp.water) {
                     const float hi[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
                     DirtyRange a, b;

@@ -44,10 +44,13 @@ struct TerrainParams {
     float water_level = 6.0f;
     uint32_t water_material = 6;
     int32_t threads = 0;
+    uint32_t coarse_depth = 0;                         // sparse refinement, see include/svo.h
+    float refine_min[3] = { 0, 0, 0 }, refine_max[3] = { 0, 0, 0 };
 };
 
 float simplex2(float x, float y);
-void  grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t depth, const HeightPyramid &pyr);
+void  grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t depth, const HeightPyramid &pyr,
+                 const TerrainParams *sparse = nullptr);
 void  fill_box(ChunkPools &c, const float lo[3], const float hi[3], uint16_t material, DirtyRange &dtree, DirtyRange &dtwig);
 int   generate_world(int w, int h, int d, int chunksize, const int chunkcoordmin[3], const TerrainParams &tp,
                      std::vector<ChunkPools> &chunks);

@@ -104,6 +104,7 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
 {
     if (!out || !tp || w <= 0 || h <= 0 || d <= 0 || chunksize <= 0) { set_error("svo_world_generate: bad argument"); return SVO_ERR_INVALID_ARG; }
     if (tp->depth < TWIG_LEVELS || tp->depth > 20) { set_error("svo_world_generate: depth must be in [2,20]"); return SVO_ERR_INVALID_ARG; }
+    if (tp->coarse_depth != 0 && (tp->coarse_depth < TWIG_LEVELS || tp->coarse_depth >= tp->depth)) { set_error("svo_world_generate: coarse_depth must be in [2, depth)"); return SVO_ERR_INVALID_ARG; }
     const uint32_t res = tp->pyramid_resolution ? tp->pyramid_resolution : (1u << tp->depth);
     if (res & (res - 1)) { set_error("svo_world_generate: pyramid_resolution must be a power of two"); return SVO_ERR_INVALID_ARG; }
     try {
@@ -115,6 +116,8 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         p.amplitude = tp->amplitude; p.yshift = tp->yshift; p.seed = tp->seed;
         p.water = tp->water; p.water_level = tp->water_level; p.water_material = tp->water_material;
         p.threads = tp->threads;
+        p.coarse_depth = tp->coarse_depth;
+        for (int i = 0; i < 3; ++i) { p.refine_min[i] = tp->refine_min[i]; p.refine_max[i] = tp->refine_max[i]; }
         generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
         classify_world(*world);
         *out = world;

@@ -176,3 +176,34 @@ def test_inexact_geometry_uses_literal(svo, oracle):
     with pytest.raises(svo.SvoError):
         W0.chunkmarch(o, d, kernel=svo.KERNEL_STACK)
     W0.destroy()
+
+
+def test_world_update_after_edits(svo, oracle):
+    """World::modify path: the oracle's restatement of Ocroot::build / destroy edits a chunk (dirty ranges = Ocdelta),
+    svo_world_update re-sends the ranges (in place, and by re-packing when the pools outgrow their slot), and the
+    march over the edited world matches the oracle again."""
+    import ctypes as C
+    O = oracle.OracleWorld.generate(2, 1, 1, 128, 6)
+    W = svo.World.create([O.chunk(i) for i in range(2)], 2, 1, 1, 128)
+    W.upload(0)
+    rng = np.random.default_rng(99)
+    o, d = random_rays(rng, 8000, (0, 0, 0), (256, 128, 128))
+    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True), O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8), "before")
+    edits = [("build", (20, 60, 20), (50, 90, 50), 5), ("destroy", (0, 0, 0), (128, 40, 30), 0),
+             ("build", (100, 100, 100), (101, 101, 101), 5), ("destroy", (30, 70, 30), (40, 80, 40), 0)]
+    for kind, lo, hi, mat in edits:
+        dt, dw = oracle.Delta(), oracle.Delta()
+        root = C.byref(O.w.chunk[0])
+        if kind == "build":
+            oracle.lib.orc_build(root, oracle.vec3(lo), oracle.vec3(hi), mat, C.byref(dt), C.byref(dw))
+        else:
+            oracle.lib.orc_destroy(root, oracle.vec3(lo), oracle.vec3(hi), C.byref(dt), C.byref(dw))
+        c = O.chunk(0)
+        W.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right),
+                 realloc=bool(dt.realloc_ or dw.realloc_))
+        want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+        for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+            assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"after {kind} {lo}")
+    # the edits really changed the picture
+    assert (want["material"] == 5).sum() > 0
+    W.destroy()
