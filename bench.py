@@ -41,6 +41,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BAND = 8                       # rows per band == tile height of the stack kernel
+STREAMS_FOR_SHARE = {1: 8, 2: 8, 4: 16, 8: 16}     # frames in flight per rank when a frame is split N ways (measured)
 
 
 def main():
@@ -50,9 +51,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3_1080p_depth12_4x1x4_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "literal", "stack"])
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight: frame i is issued on HIP stream i %% S into G-buffer i %% S, so the long-ray "
                          "tail of one frame overlaps the bulk of the next (1 = strictly serialized frames)")
+    ap.add_argument("--emulate-share", type=int, default=0,
+                    help="tuning aid (N=1 only): trace just the bands rank 0 of this many ranks would get, no exchange")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path). gloo = rehearsal of the N>1 control flow on a box with "
                          "fewer GPUs than ranks: ranks share devices and the gather is staged through host memory")
@@ -60,6 +63,9 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
     args = ap.parse_args()
 
+    # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, at most 4 frames'
+    # kernels are really in flight and 1/N-frame shares cannot hide their long-ray tails.  Must be set before HIP starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import numpy as np
     import torch                                   # before the library: one HIP runtime per process
     import torch.distributed as dist
@@ -98,13 +104,21 @@ def main():
     if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
         cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
     prm = svo.trace_params(shadow=shadow, kernel=kernel)
-    S = max(1, args.streams)
+    # frames in flight: 3 on one GPU; with N ranks every rank's share of a frame shrinks N-fold while its longest
+    # ray does not, so proportionally more frames must overlap to keep the SIMDs busy (measured with --emulate-share)
+    S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
 
     nb = svo.partition.bands_per_rank(ih, world_size, BAND)     # bands per rank (last ones may be padding)
     rec = 32
-    if world_size == 1:
+    if world_size == 1 and args.emulate_share > 1:
+        nb = svo.partition.bands_per_rank(ih, args.emulate_share, BAND)
+        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+
+        def trace(i):
+            world.trace_rows(cam, prm, 0, args.emulate_share, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
+    elif world_size == 1:
         bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
 
         def trace(i):
@@ -161,7 +175,7 @@ def main():
     # ---- untimed, rank 0 at N=1: algorithmic bytes of this frame from the reference work counters
     algo_bytes = None
     counters_sum = None
-    if world_size == 1:
+    if world_size == 1 and not args.emulate_share:
         cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
         tmp = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
         cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
@@ -198,7 +212,24 @@ def main():
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    kernel_ms_overlapped = sum(kernel_ms) / len(kernel_ms)      # per launch while S frames share the GPU
+
+    # ---- roofline leg (N=1): the kernel's own launch duration.  With frames in flight the per-launch time above
+    # measures co-scheduling (S launches share the SIMDs), so the dominant kernel is also timed back-to-back on ONE
+    # stream with HIP events on that stream; rocprofv3 --kernel-trace of `bench.py --streams 1` must agree.
+    kernel_ms_avg = kernel_ms_overlapped
+    if world_size == 1 and not args.emulate_share:
+        reps = max(5, min(args.steps, 20))
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        st0 = streams[0]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st0):
+            for a, b in sev:
+                a.record(st0)
+                world.trace(cam, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                b.record(st0)
+        st0.synchronize()
+        kernel_ms_avg = sum(a.elapsed_time(b) for a, b in sev) / reps
 
     if rank == 0 and world_size > 1:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
@@ -237,7 +268,7 @@ def main():
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }
-        if world_size == 1:
+        if world_size == 1 and not args.emulate_share:
             achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
@@ -257,6 +288,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(algo_bytes),
                 "bytes_per_ray": round(algo_bytes / rays_frame, 2),
                 "kernel_ms_avg": round(kernel_ms_avg, 5),
+                "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
                 "counters": counters_sum,
             }
             if not args.no_cpu_baseline:
