@@ -17,6 +17,7 @@
  *   svo_trace_rays       <- chunkmarch over a ray list             src/Traverse.cpp:127-171
  *   svo_world_destroy    <- World::deinit                          src/World.cpp:129-151
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
+ *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
  *
  * Conventions
  *   - plain C, opaque handle, caller owns every buffer it passes in;
@@ -181,6 +182,15 @@ int  svo_world_info_get(const svo_world *, svo_world_info *out);
 /* Borrow the host copy of chunk i (valid until the world is destroyed or chunk i is updated). */
 int  svo_world_chunk(const svo_world *, int i, svo_chunk_desc *out);
 void svo_world_destroy(svo_world *);
+
+/* Ocroot::write / Ocroot::read (src/Octree.cpp:178-201): one chunk per file, the reference's raw layout —
+ * a 64-byte header (position f32x3 @0, size f32 @12, depth u32 @16, trees u64 @24, twigs u64 @32,
+ * treestoragesize u64 @40, twigstoragesize u64 @48, modified u8 @56; the first 64 bytes of Ocroot on x86-64),
+ * then trees*4 bytes of node words, then twigs*128 bytes of bricks.  svo_chunk_read allocates *tree / *twig
+ * with malloc (caller frees with svo_chunk_free) and validates sizes against the file length. */
+int  svo_chunk_write(const char *path, const svo_chunk_desc *chunk, uint64_t treestoragesize, uint64_t twigstoragesize);
+int  svo_chunk_read(const char *path, svo_chunk_desc *out, uint64_t *treestoragesize, uint64_t *twigstoragesize);
+void svo_chunk_free(svo_chunk_desc *chunk);
 
 /* World::index_float / World::index (src/World.cpp:323-332, 288-293). */
 int  svo_world_index_float(const svo_world *, const float p[3], int q[3]);

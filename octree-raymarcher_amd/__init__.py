@@ -95,6 +95,7 @@ class WorldInfo(C.Structure):
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free",
     "svo_trace", "svo_trace_rows", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -111,6 +112,10 @@ lib.svo_world_destroy.argtypes = [_P]
 lib.svo_world_destroy.restype = None
 lib.svo_world_index_float.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]
 lib.svo_world_index.argtypes = [_P, C.c_int, C.c_int, C.c_int]
+lib.svo_chunk_write.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64]
+lib.svo_chunk_read.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+lib.svo_chunk_free.argtypes = [C.POINTER(ChunkDesc)]
+lib.svo_chunk_free.restype = None
 lib.svo_world_upload.argtypes = [_P, C.c_int]
 lib.svo_world_update.argtypes = [_P, C.c_int, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
 lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
@@ -210,6 +215,32 @@ def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0
     p.kernel = kernel
     p.counters_dev = counters_dev
     return p
+
+
+def chunk_write(path: str, chunk: dict, treestoragesize: int = 0, twigstoragesize: int = 0):
+    """Ocroot::write (src/Octree.cpp:180-187): chunk = dict(position, size, depth, tree, twig)."""
+    tree = np.ascontiguousarray(chunk["tree"], dtype=np.uint32)
+    twig = np.ascontiguousarray(chunk["twig"], dtype=np.uint16)
+    d = ChunkDesc()
+    d.position[:] = [float(x) for x in chunk["position"]]
+    d.size, d.depth = float(chunk["size"]), int(chunk["depth"])
+    d.tree, d.trees = tree.ctypes.data_as(C.POINTER(C.c_uint32)), tree.size
+    d.twig, d.twigs = twig.ctypes.data_as(C.POINTER(C.c_uint16)), twig.size // 64
+    _check(lib.svo_chunk_write(path.encode(), C.byref(d), treestoragesize, twigstoragesize), "svo_chunk_write")
+
+
+def chunk_read(path: str) -> dict:
+    """Ocroot::read (src/Octree.cpp:189-201) -> dict(position, size, depth, tree, twig, treestoragesize, twigstoragesize)."""
+    d = ChunkDesc()
+    ts, ws = C.c_uint64(), C.c_uint64()
+    _check(lib.svo_chunk_read(path.encode(), C.byref(d), C.byref(ts), C.byref(ws)), "svo_chunk_read")
+    try:
+        tree = np.ctypeslib.as_array(d.tree, shape=(d.trees,)).copy()
+        twig = np.ctypeslib.as_array(d.twig, shape=(d.twigs * 64,)).copy() if d.twigs else np.zeros(0, np.uint16)
+        return {"position": tuple(d.position), "size": d.size, "depth": d.depth, "tree": tree, "twig": twig,
+                "treestoragesize": ts.value, "twigstoragesize": ws.value}
+    finally:
+        lib.svo_chunk_free(C.byref(d))
 
 
 class World:

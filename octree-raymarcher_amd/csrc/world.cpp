@@ -9,6 +9,8 @@
 #include "world.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -195,6 +197,86 @@ void svo_world_destroy(svo_world *w)
     if (!w) return;
     release_device(*w);
     delete w;
+}
+
+// ---- Ocroot::write / read, src/Octree.cpp:178-201 ----------------------------------------------
+namespace {
+#pragma pack(push, 1)
+struct ChunkFileHeader {            // == the first 64 bytes of Ocroot (TREE_STRUCT_SIZE, src/Octree.cpp:178)
+    float    position[3];           // @0
+    float    size;                  // @12
+    uint32_t depth;                 // @16
+    uint32_t pad0;                  // @20
+    uint64_t trees, twigs;          // @24, @32
+    uint64_t treestoragesize, twigstoragesize;   // @40, @48
+    uint8_t  modified;              // @56
+    uint8_t  pad1[7];
+};
+#pragma pack(pop)
+static_assert(sizeof(ChunkFileHeader) == 64, "Ocroot file header is 64 bytes");
+}
+
+int svo_chunk_write(const char *path, const svo_chunk_desc *c, uint64_t treestoragesize, uint64_t twigstoragesize)
+{
+    if (!path || !c || !c->tree || c->trees == 0 || (c->twigs && !c->twig)) { set_error("svo_chunk_write: bad argument"); return SVO_ERR_INVALID_ARG; }
+    ChunkFileHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.position, c->position, sizeof h.position);
+    h.size = c->size; h.depth = c->depth;
+    h.trees = c->trees; h.twigs = c->twigs;
+    h.treestoragesize = treestoragesize > c->trees ? treestoragesize : c->trees;
+    h.twigstoragesize = twigstoragesize > c->twigs ? twigstoragesize : c->twigs;
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) { set_error(std::string("svo_chunk_write: cannot open ") + path); return SVO_ERR_INVALID_ARG; }
+    bool ok = std::fwrite(&h, 1, sizeof h, fp) == sizeof h &&
+              std::fwrite(c->tree, sizeof(uint32_t), c->trees, fp) == c->trees &&
+              (c->twigs == 0 || std::fwrite(c->twig, TWIG_WORDS * sizeof(uint16_t), c->twigs, fp) == c->twigs);
+    ok = (std::fclose(fp) == 0) && ok;
+    if (!ok) { set_error("svo_chunk_write: short write"); return SVO_ERR_INVALID_ARG; }
+    return SVO_OK;
+}
+
+int svo_chunk_read(const char *path, svo_chunk_desc *out, uint64_t *treestoragesize, uint64_t *twigstoragesize)
+{
+    if (!path || !out) { set_error("svo_chunk_read: bad argument"); return SVO_ERR_INVALID_ARG; }
+    std::memset(out, 0, sizeof *out);
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) { set_error(std::string("svo_chunk_read: cannot open ") + path); return SVO_ERR_INVALID_ARG; }
+    ChunkFileHeader h;
+    int rc = SVO_OK;
+    uint32_t *tree = nullptr;
+    uint16_t *twig = nullptr;
+    do {
+        if (std::fread(&h, 1, sizeof h, fp) != sizeof h) { set_error("svo_chunk_read: truncated header"); rc = SVO_ERR_MALFORMED_TREE; break; }
+        std::fseek(fp, 0, SEEK_END);
+        const long long len = std::ftell(fp);
+        std::fseek(fp, (long)sizeof h, SEEK_SET);
+        // the reference trusts the header (src/Octree.cpp:189-201); here sizes are checked against the file
+        if (h.trees == 0 || h.trees > (1ull << 31) || h.twigs > (1ull << 31) ||
+            (unsigned long long)len != sizeof h + h.trees * 4ull + h.twigs * 128ull) { set_error("svo_chunk_read: header does not match file length"); rc = SVO_ERR_MALFORMED_TREE; break; }
+        tree = (uint32_t *)std::malloc(h.trees * sizeof(uint32_t));
+        twig = (uint16_t *)std::malloc((h.twigs ? h.twigs : 1) * TWIG_WORDS * sizeof(uint16_t));
+        if (!tree || !twig) { set_error("svo_chunk_read: out of memory"); rc = SVO_ERR_OUT_OF_MEMORY; break; }
+        if (std::fread(tree, sizeof(uint32_t), h.trees, fp) != h.trees ||
+            (h.twigs && std::fread(twig, TWIG_WORDS * sizeof(uint16_t), h.twigs, fp) != h.twigs)) { set_error("svo_chunk_read: short read"); rc = SVO_ERR_MALFORMED_TREE; break; }
+    } while (0);
+    std::fclose(fp);
+    if (rc != SVO_OK) { std::free(tree); std::free(twig); return rc; }
+    std::memcpy(out->position, h.position, sizeof out->position);
+    out->size = h.size; out->depth = h.depth;
+    out->tree = tree; out->trees = h.trees;
+    out->twig = twig; out->twigs = h.twigs;
+    if (treestoragesize) *treestoragesize = h.treestoragesize;
+    if (twigstoragesize) *twigstoragesize = h.twigstoragesize;
+    return SVO_OK;
+}
+
+void svo_chunk_free(svo_chunk_desc *c)
+{
+    if (!c) return;
+    std::free(const_cast<uint32_t *>(c->tree));
+    std::free(const_cast<uint16_t *>(c->twig));
+    c->tree = nullptr; c->twig = nullptr; c->trees = c->twigs = 0;
 }
 
 int svo_world_index_float(const svo_world *w, const float p[3], int q[3])

@@ -80,5 +80,13 @@ def test_integer_cell_coordinates_reproduce_float_descent():
         u = np.minimum(u, 2**levels - 1)
         u -= ((np.float32(pos) + u.astype(np.float32) * cell).astype(np.float32) > p)
         assert np.array_equal(u, ref)
+        # kernel v4 form: plain truncation, compare-and-fix only where the quotient is integral
+        f = ((p - np.float32(pos)).astype(np.float32) * inv).astype(np.float32)
+        u2 = f.astype(np.int64)
+        integral = f == u2.astype(np.float32)
+        uc = np.minimum(u2, 2**levels - 1)
+        uc = uc - ((np.float32(pos) + uc.astype(np.float32) * cell).astype(np.float32) > p)
+        u2 = np.where(integral, uc, u2)
+        assert np.array_equal(u2, ref) and integral.sum() > 100
         # the node box rebuilt from the coordinates equals the incrementally accumulated bmin
         assert np.array_equal((np.float32(pos) + u.astype(np.float32) * cell).astype(np.float32), lo)
