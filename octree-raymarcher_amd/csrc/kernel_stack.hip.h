@@ -36,6 +36,9 @@ namespace svo {
 
 enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 
+#ifndef SVO_CREEP_ROUNDS
+#define SVO_CREEP_ROUNDS 0       // >0: consecutive same-cell ("creeping") steps taken inside one iteration
+#endif
 #ifndef SVO_VOTE_WORLD
 #define SVO_VOTE_WORLD 12        // lanes waiting for a chunk step that make the wave run it
 #endif
@@ -361,9 +364,31 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const V3 E_p = leave ? O : p;
                 const V3 E_lo = leave ? Blo : mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                 const float E_size = leave ? Bsize : res * (float)(low + 1);
-                const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
+                float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
                 if (!leave) {
                     t += e;
+#if SVO_CREEP_ROUNDS > 0
+                    // A ray pinned on a lattice plane creeps: escape ~ 0, t grows by EPS per step (the reference's CPU path has
+                    // no BIGEPS guard, shaders/Chunkmarch.glsl:113).  While the next position stays in the cell just located,
+                    // the next reference step is fully determined (same node word / same empty brick cell): take it here.
+                    for (int r = 0; e < 2.0f * eps && r < SVO_CREEP_ROUNDS && cnt < (twig ? A.cap_twig : A.cap_tree) && guard < STEP_GUARD; ++r) {
+                        const V3 q = O + beta * t;
+                        if (!inside(q, Blo, Blo + Bsize)) break;
+                        const float qx = (q.x - Blo.x) * inv_res, qy = (q.y - Blo.y) * inv_res, qz = (q.z - Blo.z) * inv_res;
+                        int vx = (int)qx, vy = (int)qy, vz = (int)qz;
+                        if (!twig && ((qx == (float)vx) | (qy == (float)vy) | (qz == (float)vz))) {
+                            const int nmax = (1 << levels) - 1;
+                            vx = vx > nmax ? nmax : vx; vy = vy > nmax ? nmax : vy; vz = vz > nmax ? nmax : vz;
+                            vx -= (Blo.x + (float)vx * res > q.x) ? 1 : 0;
+                            vy -= (Blo.y + (float)vy * res > q.y) ? 1 : 0;
+                            vz -= (Blo.z + (float)vz * res > q.z) ? 1 : 0;
+                        }
+                        if ((((vx ^ ux) | (vy ^ uy) | (vz ^ uz)) & ~low) != 0) break;       // left the cell
+                        cnt++; guard++;
+                        e = escape(q, g, E_lo, E_lo + E_size) + eps;
+                        t += e;
+                    }
+#endif
                 } else if (twig) {                                  // back to the tree level that entered the brick
                     t = tt_saved + e;
                     cnt = it_saved;
