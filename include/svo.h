@@ -97,6 +97,9 @@ typedef struct svo_terrain_params {
     uint32_t coarse_depth;
     float    refine_min[3];
     float    refine_max[3];
+    /* 0 = generate on host threads; k > 0 = generate on HIP device k-1 (noise, mips and the level-synchronous
+     * BFS as kernels, bit-identical pools; only the water fill stays on the host). */
+    int32_t  build_device_plus1;
 } svo_terrain_params;
 
 /* Pinhole camera of the build (the reference rasterises the world box and uses

@@ -69,7 +69,7 @@ class TerrainParams(C.Structure):
     _fields_ = [("depth", C.c_uint32), ("pyramid_resolution", C.c_uint32), ("amplitude", C.c_float),
                 ("yshift", C.c_float), ("seed", C.c_int32), ("water", C.c_int32), ("water_level", C.c_float),
                 ("water_material", C.c_uint32), ("threads", C.c_int32), ("coarse_depth", C.c_uint32),
-                ("refine_min", C.c_float * 3), ("refine_max", C.c_float * 3)]
+                ("refine_min", C.c_float * 3), ("refine_max", C.c_float * 3), ("build_device_plus1", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -254,13 +254,14 @@ class World:
     def generate(cls, w: int, h: int, d: int, chunksize: int = 128, depth: int = 8, chunkcoordmin=(0, 0, 0),
                  pyramid_resolution: int = 0, amplitude: float = 64.0, yshift: float = 16.0, seed: int = 0,
                  water: bool = True, water_level: float = 6.0, water_material: int = 6, threads: int = 0,
-                 coarse_depth: int = 0, refine_box=None) -> "World":
+                 coarse_depth: int = 0, refine_box=None, build_device: Optional[int] = None) -> "World":
         """coarse_depth / refine_box=((x0,y0,z0),(x1,y1,z1)): sparse refinement (full depth only inside the box)."""
         tp = TerrainParams(depth, pyramid_resolution, amplitude, yshift, seed, 1 if water else 0, water_level,
                            water_material, threads, coarse_depth)
         if refine_box is not None:
             tp.refine_min[:] = [float(v) for v in refine_box[0]]
             tp.refine_max[:] = [float(v) for v in refine_box[1]]
+        tp.build_device_plus1 = 0 if build_device is None else int(build_device) + 1     # None: host threads
         ccm = (C.c_int * 3)(*chunkcoordmin)
         out = _P()
         _check(lib.svo_world_generate(w, h, d, chunksize, ccm, C.byref(tp), C.byref(out)), "svo_world_generate")

@@ -54,5 +54,8 @@ void  grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t de
 void  fill_box(ChunkPools &c, const float lo[3], const float hi[3], uint16_t material, DirtyRange &dtree, DirtyRange &dtwig);
 int   generate_world(int w, int h, int d, int chunksize, const int chunkcoordmin[3], const TerrainParams &tp,
                      std::vector<ChunkPools> &chunks);
+// the same world built on HIP device `device` (builder.hip); returns an svo_status
+int   generate_world_device(int device, int w, int h, int d, int chunksize, const int chunkcoordmin[3], const TerrainParams &tp,
+                            std::vector<ChunkPools> &chunks);
 
 } // namespace svo

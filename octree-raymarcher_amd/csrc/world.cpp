@@ -120,7 +120,12 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         p.threads = tp->threads;
         p.coarse_depth = tp->coarse_depth;
         for (int i = 0; i < 3; ++i) { p.refine_min[i] = tp->refine_min[i]; p.refine_max[i] = tp->refine_max[i]; }
-        generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
+        if (tp->build_device_plus1 > 0) {
+            const int rc = generate_world_device(tp->build_device_plus1 - 1, w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
+            if (rc != SVO_OK) { delete world; return rc; }
+        } else {
+            generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
+        }
         classify_world(*world);
         *out = world;
         return SVO_OK;
