@@ -18,6 +18,7 @@
  *   svo_world_destroy    <- World::deinit                          src/World.cpp:129-151
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
  *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
+ *   svo_world_shift      <- World::shift                           src/World.cpp:334-378
  *
  * Conventions
  *   - plain C, opaque handle, caller owns every buffer it passes in;
@@ -211,6 +212,11 @@ int svo_world_upload(svo_world *, int device);
 int svo_world_update(svo_world *, int chunk, const svo_chunk_desc *desc,
                      uint64_t tree_left, uint64_t tree_right,
                      uint64_t twig_left, uint64_t twig_right, int realloc);
+
+/* World::shift (src/World.cpp:334-378): slide the grid by one chunk along one axis (offset = +-1 on exactly one
+ * axis).  The entering plane of chunks is generated with the world's terrain parameters and replaces, at its
+ * toroidal World::index(), the plane that leaves; chunkcoordmin moves.  Only for worlds made by svo_world_generate. */
+int svo_world_shift(svo_world *, const int offset[3]);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 

@@ -95,7 +95,7 @@ class WorldInfo(C.Structure):
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
-    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift",
     "svo_trace", "svo_trace_rows", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -116,6 +116,7 @@ lib.svo_chunk_write.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.c_uint64, C.
 lib.svo_chunk_read.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 lib.svo_chunk_free.argtypes = [C.POINTER(ChunkDesc)]
 lib.svo_chunk_free.restype = None
+lib.svo_world_shift.argtypes = [_P, C.POINTER(C.c_int)]
 lib.svo_world_upload.argtypes = [_P, C.c_int]
 lib.svo_world_update.argtypes = [_P, C.c_int, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
 lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
@@ -340,6 +341,11 @@ class World:
         d.twig, d.twigs = twig.ctypes.data_as(C.POINTER(C.c_uint16)), twig.size // 64
         _check(lib.svo_world_update(self._h, chunk, C.byref(d), tree_range[0], tree_range[1], twig_range[0], twig_range[1],
                                     1 if realloc else 0), "svo_world_update")
+
+    def shift(self, offset):
+        """World::shift (src/World.cpp:334-378): slide the grid one chunk along one axis."""
+        off = (C.c_int * 3)(*[int(v) for v in offset])
+        _check(lib.svo_world_shift(self._h, off), "svo_world_shift")
 
     # raw launches on caller-owned device memory (bench.py passes torch tensors' data_ptr())
     def trace(self, cam: Camera, params: TraceParams, rect, out_ptr: int, stream: int = 0):

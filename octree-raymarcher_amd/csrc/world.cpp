@@ -126,6 +126,8 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         } else {
             generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
         }
+        world->terrain = p;
+        world->has_terrain = true;
         classify_world(*world);
         *out = world;
         return SVO_OK;
@@ -168,6 +170,58 @@ int svo_world_create(const svo_chunk_desc *chunks, int n, int w, int h, int d, i
         set_error("svo_world_create: out of host memory");
         return SVO_ERR_OUT_OF_MEMORY;
     }
+}
+
+// World::shift, src/World.cpp:334-378: slide the grid one chunk along one axis.  The plane of chunks entering
+// the grid is generated (g_pyramid + g_chunk) and stored at its toroidal index — where the plane leaving on the
+// opposite side used to live — then chunkcoordmin moves.  Device copies are refreshed through svo_world_update.
+int svo_world_shift(svo_world *w, const int offset[3])
+{
+    if (!w || !offset) return SVO_ERR_INVALID_ARG;
+    if (!w->has_terrain) { set_error("svo_world_shift: world was not made by svo_world_generate (no terrain parameters)"); return SVO_ERR_UNSUPPORTED; }
+    int axis = -1;
+    for (int a = 0; a < 3; ++a)
+        if (offset[a] != 0) { if (axis >= 0 || (offset[a] != 1 && offset[a] != -1)) { set_error("svo_world_shift: offset must be a unit axis step"); return SVO_ERR_INVALID_ARG; } axis = a; }
+    if (axis < 0) { set_error("svo_world_shift: offset must be a unit axis step"); return SVO_ERR_INVALID_ARG; }
+    const int sign = offset[axis];
+    const int dims[3] = { w->width, w->height, w->depth };
+    const int u = sign < 0 ? w->chunkcoordmin[axis] - 1 : w->chunkcoordmin[axis] + dims[axis];
+    const TerrainParams &tp = w->terrain;
+    const uint32_t res = tp.pyramid_resolution ? tp.pyramid_resolution : (1u << tp.depth);
+    try {
+        // entering plane: all chunk coordinates with coordinate[axis] == u; columns (cx, cz) share a pyramid
+        int lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = w->chunkcoordmin[a]; hi[a] = w->chunkcoordmin[a] + dims[a]; }
+        lo[axis] = u; hi[axis] = u + 1;
+        HeightPyramid pyr;
+        for (int cz = lo[2]; cz < hi[2]; ++cz)
+            for (int cx = lo[0]; cx < hi[0]; ++cx) {
+                pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift, (float)cz * (float)res + (float)tp.seed);
+                for (int cy = lo[1]; cy < hi[1]; ++cy) {
+                    ChunkPools c;
+                    const float pos[3] = { (float)cx * (float)w->chunksize, (float)cy * (float)w->chunksize, (float)cz * (float)w->chunksize };
+                    grow_chunk(c, pos, (float)w->chunksize, tp.depth, pyr, &tp);
+                    if (tp.water) {
+                        const float top[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
+                        DirtyRange a, b;
+                        fill_box(c, c.position, top, (uint16_t)tp.water_material, a, b);
+                    }
+                    svo_chunk_desc d;
+                    std::memcpy(d.position, c.position, sizeof d.position);
+                    d.size = c.size; d.depth = c.depth; d._pad = 0;
+                    d.tree = c.tree.data(); d.trees = c.tree.size();
+                    d.twig = c.twig.data(); d.twigs = c.twig_count();
+                    const int idx = svo_world_index(w, cx, cy, cz);
+                    const int rc = svo_world_update(w, idx, &d, 0, d.trees, 0, d.twigs, 1);
+                    if (rc != SVO_OK) return rc;
+                }
+            }
+    } catch (const std::bad_alloc &) {
+        set_error("svo_world_shift: out of host memory");
+        return SVO_ERR_OUT_OF_MEMORY;
+    }
+    w->chunkcoordmin[axis] += sign;
+    return SVO_OK;
 }
 
 int svo_world_info_get(const svo_world *w, svo_world_info *o)

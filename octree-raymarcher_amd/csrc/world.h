@@ -11,6 +11,8 @@ struct svo_world {
     int width = 0, height = 0, depth = 0, chunksize = 0;
     int chunkcoordmin[3] = { 0, 0, 0 };
     std::vector<svo::ChunkPools> chunks;          // World::index() order
+    svo::TerrainParams terrain;                   // generator parameters (svo_world_generate), for svo_world_shift
+    bool has_terrain = false;
 
     // geometry class
     bool exact_geometry = false;                  // every voxel corner is an exact float
