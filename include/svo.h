@@ -19,6 +19,7 @@
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
  *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
  *   svo_world_shift      <- World::shift                           src/World.cpp:334-378
+ *   svo_shade            <- lighting of fragment main               shaders/World.Fragment.glsl:63-138,180-197
  *
  * Conventions
  *   - plain C, opaque handle, caller owns every buffer it passes in;
@@ -237,6 +238,30 @@ int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *p
 /* chunkmarch over an explicit list: origins_dev/dirs_dev are [n][3] float on the device. */
 int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev, int64_t n,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);
+
+/* ---- shading stage: Blinn-Phong x 3 lights over the G-buffer --------------------
+ * shaders/World.Fragment.glsl:63-138,180-197.  The reference multiplies the lights with gamma-decoded samples of
+ * its Diffuse / Specular texture atlas, which is not part of the repository; here the albedo comes from the
+ * material table's diffuse / specular colours instead (pow(colour, gamma)), the shadow term from SVO_SHADOWED.
+ * Output per pixel: float4 {r, g, b, depth} with depth = (1/dist - 1/near) / (1/far - 1/near) (gl_FragDepth,
+ * World.Fragment.glsl:193-197); misses give {0,0,0,1}. */
+typedef struct svo_material { float ambient[3], diffuse[3], specular[3]; float shininess; } svo_material;
+typedef struct svo_shade_params {
+    struct { float position[3], ambient[3], diffuse[3], specular[3]; float constant, linear, quadratic; } point;
+    struct { float position[3], direction[3], ambient[3], diffuse[3], specular[3]; } directional;
+    struct { float position[3], direction[3], ambient[3], diffuse[3], specular[3];
+             float cos_phi, cos_gamma, constant, linear, quadratic; } spot;
+    svo_material materials[8];      /* ML[8], World.Fragment.glsl:63-73 */
+    float eps;                      /* 0 = 1/8192 */
+    float gamma;                    /* 0 = 2.2 */
+    float near_plane, far_plane;    /* 0 = 0.125 / 8192 (shaders/Chunkmarch.glsl:20-21) */
+} svo_shade_params;
+
+/* Fill `p` with the reference's lights (src/Main.cpp:101-131) and material table. */
+void svo_shade_defaults(svo_shade_params *p);
+/* Shade the rectangle a svo_trace(cam, x0, y0, w, h) call filled: gbuffer_dev has w*h records, rgba_dev w*h float4. */
+int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+              const svo_hit *gbuffer_dev, float *rgba_dev, void *stream);
 
 /* Number of rays the last svo_trace* call on this world actually marched (primary + shadow);
  * synchronises `stream` internally — call it outside timed regions. */

@@ -83,6 +83,31 @@ class TraceParams(C.Structure):
                 ("kernel", C.c_int32), ("_pad", C.c_int32), ("counters_dev", C.c_void_p)]
 
 
+class Material(C.Structure):
+    _fields_ = [("ambient", C.c_float * 3), ("diffuse", C.c_float * 3), ("specular", C.c_float * 3), ("shininess", C.c_float)]
+
+
+class _PointLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("ambient", C.c_float * 3), ("diffuse", C.c_float * 3), ("specular", C.c_float * 3),
+                ("constant", C.c_float), ("linear", C.c_float), ("quadratic", C.c_float)]
+
+
+class _DirectionalLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3), ("ambient", C.c_float * 3), ("diffuse", C.c_float * 3),
+                ("specular", C.c_float * 3)]
+
+
+class _Spotlight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("direction", C.c_float * 3), ("ambient", C.c_float * 3), ("diffuse", C.c_float * 3),
+                ("specular", C.c_float * 3), ("cos_phi", C.c_float), ("cos_gamma", C.c_float), ("constant", C.c_float),
+                ("linear", C.c_float), ("quadratic", C.c_float)]
+
+
+class ShadeParams(C.Structure):
+    _fields_ = [("point", _PointLight), ("directional", _DirectionalLight), ("spot", _Spotlight), ("materials", Material * 8),
+                ("eps", C.c_float), ("gamma", C.c_float), ("near_plane", C.c_float), ("far_plane", C.c_float)]
+
+
 class WorldInfo(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_int32), ("chunksize", C.c_int32),
                 ("chunkcoordmin", C.c_int32 * 3), ("uploaded_device", C.c_int32),
@@ -95,7 +120,7 @@ class WorldInfo(C.Structure):
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
-    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_defaults",
     "svo_trace", "svo_trace_rows", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -117,6 +142,9 @@ lib.svo_chunk_read.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.POINTER(C.c_u
 lib.svo_chunk_free.argtypes = [C.POINTER(ChunkDesc)]
 lib.svo_chunk_free.restype = None
 lib.svo_world_shift.argtypes = [_P, C.POINTER(C.c_int)]
+lib.svo_shade_defaults.argtypes = [C.POINTER(ShadeParams)]
+lib.svo_shade_defaults.restype = None
+lib.svo_shade.argtypes = [C.POINTER(Camera), C.POINTER(ShadeParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]
 lib.svo_world_upload.argtypes = [_P, C.c_int]
 lib.svo_world_update.argtypes = [_P, C.c_int, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
 lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
@@ -242,6 +270,18 @@ def chunk_read(path: str) -> dict:
                 "treestoragesize": ts.value, "twigstoragesize": ws.value}
     finally:
         lib.svo_chunk_free(C.byref(d))
+
+
+def shade_defaults() -> ShadeParams:
+    """The reference's lights (src/Main.cpp:101-131) and material table (shaders/World.Fragment.glsl:63-73)."""
+    p = ShadeParams()
+    lib.svo_shade_defaults(C.byref(p))
+    return p
+
+
+def shade(cam: Camera, params: ShadeParams, rect, gbuffer_ptr: int, rgba_ptr: int, stream: int = 0):
+    x0, y0, w, h = rect
+    _check(lib.svo_shade(C.byref(cam), C.byref(params), x0, y0, w, h, gbuffer_ptr, rgba_ptr, stream), "svo_shade")
 
 
 class World:

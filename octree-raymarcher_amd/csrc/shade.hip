@@ -1,0 +1,159 @@
+// shade.hip — the shading stage over the G-buffer: Blinn-Phong x 3 lights,
+// shaders/World.Fragment.glsl:63-138,180-197, as one coalesced kernel (32 B read + 16 B written per pixel:
+// HBM-bound).  Albedo from the material table instead of the (unavailable) texture atlas — see include/svo.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "march.hip.h"
+#include "world.h"
+
+namespace svo {
+namespace {
+
+struct ShadeArgs {
+    svo_shade_params P;
+    float eye[3], fwd[3], right[3], up[3];
+    float tanx, tany;
+    int32_t imgw, imgh, x0, y0, w, h;
+    const uint4 *gbuffer;
+    float4 *rgba;
+};
+
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length3(V3 v) { return sqrtf(dot3(v, v)); }
+__device__ __forceinline__ V3 neg(V3 v) { return mk(-v.x, -v.y, -v.z); }
+__device__ __forceinline__ float maxf0(float x) { return (x < 0.0f) ? 0.0f : x; }          // max(x, 0.0)
+__device__ __forceinline__ V3 pow3(V3 v, float e) { return mk(powf(v.x, e), powf(v.y, e), powf(v.z, e)); }
+__device__ __forceinline__ float attenuation(float kc, float kl, float kq, float d) { return 1.0f / (kc + kl * d + kq * d * d); }   // :75-78
+
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (int64_t)A.w * A.h) return;
+    const uint4 r0 = A.gbuffer[2 * k], r1 = A.gbuffer[2 * k + 1];
+    const uint32_t flags = r1.x >> 16, material = r1.x & 0xFFFFu;
+    if (!(flags & SVO_HIT_FLAG)) { A.rgba[k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }       // discard
+    const svo_shade_params &P = A.P;
+    // the ray of this pixel (same generation as the march) and the shaded point alpha + beta * (sigma - EPS), :174
+    const int px = A.x0 + (int)(k % A.w), py = A.y0 + (int)(k / A.w);
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float u = ((fx / (float)A.imgw) * 2.0f - 1.0f) * A.tanx;
+    const float v = (1.0f - (fy / (float)A.imgh) * 2.0f) * A.tany;
+    const V3 eye = ld3(A.eye);
+    const V3 beta = normalize3((ld3(A.fwd) + ld3(A.right) * u) + ld3(A.up) * v);
+    const float t = __uint_as_float(r0.x);
+    const V3 p = eye + beta * (t - P.eps);
+    const V3 n = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+    const svo_material &M = P.materials[material < 8 ? material : 0];
+    const V3 diffuse = pow3(ld3(M.diffuse), P.gamma), specular = pow3(ld3(M.specular), P.gamma);     // :183-184
+    const float lit = (flags & SVO_SHADOWED) ? 0.0f : 1.0f;                                          // (1.0 - shadow)
+    const V3 vdir = normalize3(eye - p);
+    V3 color = mk(0.0f, 0.0f, 0.0f);
+    {   // computePointLight_BlinnPhong, :80-97
+        const V3 l = normalize3(ld3(P.point.position) - p);
+        const V3 hv = normalize3(l + vdir);
+        const float d = maxf0(dot3(n, l));
+        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
+        const float att = attenuation(P.point.constant, P.point.linear, P.point.quadratic, length3(p - ld3(P.point.position)));
+        const V3 amb = ld3(P.point.ambient) * diffuse;
+        const V3 dif = ((ld3(P.point.diffuse) * d) * diffuse) * lit;
+        const V3 spe = ((ld3(P.point.specular) * s) * specular) * lit;
+        color = color + ((amb + dif) + spe) * att;
+    }
+    {   // computeDirectionalLight_BlinnPhong, :99-114
+        const V3 l = normalize3(neg(ld3(P.directional.direction)));
+        const V3 hv = normalize3(l + vdir);
+        const float d = maxf0(dot3(n, l));
+        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
+        const V3 amb = ld3(P.directional.ambient) * diffuse;
+        const V3 dif = ((ld3(P.directional.diffuse) * d) * diffuse) * lit;
+        const V3 spe = ((ld3(P.directional.specular) * s) * specular) * lit;
+        color = color + ((amb + dif) + spe);
+    }
+    {   // computeSpotlight_BlinnPhong, :116-138
+        const V3 l = normalize3(ld3(P.spot.position) - p);
+        const V3 hv = normalize3(l + vdir);
+        const float d = maxf0(dot3(n, l));
+        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
+        const float att = attenuation(P.spot.constant, P.spot.linear, P.spot.quadratic, length3(p - ld3(P.spot.position)));
+        const float theta = dot3(l, normalize3(neg(ld3(P.spot.direction))));
+        const float delta = P.spot.cos_phi - P.spot.cos_gamma;
+        float intensity = (theta - P.spot.cos_gamma) / delta;
+        intensity = (intensity < 0.0f) ? 0.0f : intensity;                      // clamp = min(max(x, 0), 1)
+        intensity = (1.0f < intensity) ? 1.0f : intensity;
+        const V3 amb = ld3(P.spot.ambient) * diffuse;
+        const V3 dif = ((ld3(P.spot.diffuse) * d) * diffuse) * lit;
+        const V3 spe = ((ld3(P.spot.specular) * s) * specular) * lit;
+        color = color + (amb + (dif + spe) * intensity) * att;
+    }
+    const float inv_z = 1.0f / length3(p - eye), inv_near = 1.0f / P.near_plane, inv_far = 1.0f / P.far_plane;     // :193-197
+    A.rgba[k] = make_float4(color.x, color.y, color.z, (inv_z - inv_near) / (inv_far - inv_near));
+}
+
+} // namespace
+} // namespace svo
+
+using namespace svo;
+
+extern "C" {
+
+void svo_shade_defaults(svo_shade_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    auto set3 = [](float *d, float x, float y, float z) { d[0] = x; d[1] = y; d[2] = z; };
+    // src/Main.cpp:101-109
+    set3(p->point.position, 50, 8, 65); set3(p->point.ambient, 0.1f, 0.1f, 0.1f); set3(p->point.diffuse, 0.5f, 0.5f, 0.5f); set3(p->point.specular, 1, 1, 1);
+    p->point.constant = 1.0f; p->point.linear = 0.14f; p->point.quadratic = 0.09f;
+    // :114-119
+    const float inv = 1.0f / std::sqrt(2.0f);
+    set3(p->directional.position, 250, 125, 250); set3(p->directional.direction, inv, -inv, 0.0f);
+    set3(p->directional.ambient, 0.2f, 0.3f, 0.4f); set3(p->directional.diffuse, 0.3f, 0.3f, 0.6f); set3(p->directional.specular, 0, 0, 0);
+    // :121-131
+    const float sl = 1.0f / std::sqrt(0.01f + 1.0f + 0.01f);
+    set3(p->spot.position, 50, 20, 70); set3(p->spot.direction, -0.1f * sl, -1.0f * sl, -0.1f * sl);
+    set3(p->spot.ambient, 0.2f, 0.8f, 0.3f); set3(p->spot.diffuse, 0.2f, 0.8f, 0.3f); set3(p->spot.specular, 1, 1, 1);
+    p->spot.cos_phi = (float)std::cos(25.0 * 3.14159265358979323846 / 180.0);
+    p->spot.cos_gamma = (float)std::cos(35.0 * 3.14159265358979323846 / 180.0);
+    p->spot.constant = 1.0f; p->spot.linear = 0.045f; p->spot.quadratic = 0.0075f;
+    // ML[8], shaders/World.Fragment.glsl:63-73
+    const float ml[8][10] = {
+        { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, { .8f, .8f, .8f, .8f, .8f, .8f, .5f, .5f, .5f, 8 }, { .8f, .8f, .8f, .6f, .6f, .6f, .1f, .1f, .1f, 16 },
+        { .8f, .8f, .8f, .7f, .7f, .7f, .15f, .15f, .15f, 32 }, { .8f, .8f, .8f, .9f, .9f, .9f, .7f, .7f, .7f, 10000 },
+        { .8f, .8f, .8f, .5f, .5f, .5f, 0, 0, 0, 0 }, { .8f, .8f, .8f, .4f, .4f, .4f, 1, 1, 1, 100 }, { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 } };
+    for (int i = 0; i < 8; ++i) {
+        std::memcpy(p->materials[i].ambient, &ml[i][0], 12); std::memcpy(p->materials[i].diffuse, &ml[i][3], 12);
+        std::memcpy(p->materials[i].specular, &ml[i][6], 12); p->materials[i].shininess = ml[i][9];
+    }
+    p->eps = 1.0f / 8192.0f; p->gamma = 2.2f; p->near_plane = 0.125f; p->far_plane = 8192.0f;
+}
+
+int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+              const svo_hit *gbuffer_dev, float *rgba_dev, void *stream)
+{
+    if (!cam || !p || !gbuffer_dev || !rgba_dev || w < 0 || h < 0 || x0 < 0 || y0 < 0 || cam->width <= 0 || cam->height <= 0) {
+        set_error("svo_shade: bad argument"); return SVO_ERR_INVALID_ARG;
+    }
+    ShadeArgs A;
+    A.P = *p;
+    if (A.P.eps == 0.0f) A.P.eps = 1.0f / 8192.0f;
+    if (A.P.gamma == 0.0f) A.P.gamma = 2.2f;
+    if (A.P.near_plane == 0.0f) A.P.near_plane = 0.125f;
+    if (A.P.far_plane == 0.0f) A.P.far_plane = 8192.0f;
+    std::memcpy(A.eye, cam->eye, 12); std::memcpy(A.fwd, cam->forward, 12); std::memcpy(A.right, cam->right, 12); std::memcpy(A.up, cam->up, 12);
+    A.tanx = cam->tan_half_x; A.tany = cam->tan_half_y; A.imgw = cam->width; A.imgh = cam->height;
+    A.x0 = x0; A.y0 = y0; A.w = w; A.h = h;
+    A.gbuffer = reinterpret_cast<const uint4 *>(gbuffer_dev);
+    A.rgba = reinterpret_cast<float4 *>(rgba_dev);
+    const int64_t n = (int64_t)w * h;
+    if (n == 0) return SVO_OK;
+    hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("svo_shade: ") + hipGetErrorString(e)); return e == hipErrorNoDevice ? SVO_ERR_NO_DEVICE : SVO_ERR_HIP; }
+    return SVO_OK;
+}
+
+} // extern "C"

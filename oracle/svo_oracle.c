@@ -835,3 +835,72 @@ uint64_t orc_trace_image(const orc_world *w, const orc_camera *cam, const orc_pa
     j.w = w; j.prm = prm; j.cam = cam; j.x0 = x0; j.y0 = y0; j.rw = rw; j.rh = rh; j.out = out; j.cnt = cnt;
     return run_jobs(j, threads);
 }
+
+/* ================================================================ shading stage ============ */
+/* shaders/World.Fragment.glsl:75-138 (attenuation, three Blinn-Phong lights) and :180-197 (main), with the
+ * albedo taken from the material table (the texture atlas is not part of the reference repository). */
+static float v3length(vec3 v) { return sqrtf(v3dot(v, v)); }
+static vec3 v3neg(vec3 v) { return v3(-v.x, -v.y, -v.z); }
+static vec3 v3pow(vec3 v, float e) { return v3(powf(v.x, e), powf(v.y, e), powf(v.z, e)); }
+static vec3 f3(const float *p) { return v3(p[0], p[1], p[2]); }
+static float attenuation(float kc, float kl, float kq, float d) { return 1.0f / (kc + kl * d + kq * d * d); }
+static float max0(float x) { return gmax(x, 0.0f); }
+
+void orc_shade_image(const orc_camera *cam, const orc_shade_params *P, int x0, int y0, int w, int h,
+                     const orc_hit *gbuffer, float *rgba)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int64_t k = (int64_t)y * w + x;
+            const orc_hit *r = &gbuffer[k];
+            float *out = rgba + 4 * k;
+            if (!(r->flags & HIT_FLAG)) { out[0] = out[1] = out[2] = 0.0f; out[3] = 1.0f; continue; }
+            vec3 eye, beta;
+            orc_camera_ray(cam, x0 + x, y0 + y, &eye, &beta);
+            const vec3 p = v3add(eye, v3muls(beta, r->t - P->eps));
+            const vec3 n = v3(r->normal[0], r->normal[1], r->normal[2]);
+            const orc_material *M = &P->materials[r->material < 8 ? r->material : 0];
+            const vec3 diffuse = v3pow(f3(M->diffuse), P->gamma), specular = v3pow(f3(M->specular), P->gamma);
+            const float lit = (r->flags & SHADOWED) ? 0.0f : 1.0f;
+            const vec3 vdir = v3normalize(v3sub(eye, p));
+            vec3 color = v3(0, 0, 0);
+            {
+                const vec3 l = v3normalize(v3sub(f3(P->point.position), p));
+                const vec3 hv = v3normalize(v3add(l, vdir));
+                const float d = max0(v3dot(n, l));
+                const float s = powf(max0(v3dot(vdir, hv)), M->shininess);
+                const float att = attenuation(P->point.constant, P->point.linear, P->point.quadratic, v3length(v3sub(p, f3(P->point.position))));
+                const vec3 amb = v3mul(f3(P->point.ambient), diffuse);
+                const vec3 dif = v3muls(v3mul(v3muls(f3(P->point.diffuse), d), diffuse), lit);
+                const vec3 spe = v3muls(v3mul(v3muls(f3(P->point.specular), s), specular), lit);
+                color = v3add(color, v3muls(v3add(v3add(amb, dif), spe), att));
+            }
+            {
+                const vec3 l = v3normalize(v3neg(f3(P->directional.direction)));
+                const vec3 hv = v3normalize(v3add(l, vdir));
+                const float d = max0(v3dot(n, l));
+                const float s = powf(max0(v3dot(vdir, hv)), M->shininess);
+                const vec3 amb = v3mul(f3(P->directional.ambient), diffuse);
+                const vec3 dif = v3muls(v3mul(v3muls(f3(P->directional.diffuse), d), diffuse), lit);
+                const vec3 spe = v3muls(v3mul(v3muls(f3(P->directional.specular), s), specular), lit);
+                color = v3add(color, v3add(v3add(amb, dif), spe));
+            }
+            {
+                const vec3 l = v3normalize(v3sub(f3(P->spot.position), p));
+                const vec3 hv = v3normalize(v3add(l, vdir));
+                const float d = max0(v3dot(n, l));
+                const float s = powf(max0(v3dot(vdir, hv)), M->shininess);
+                const float att = attenuation(P->spot.constant, P->spot.linear, P->spot.quadratic, v3length(v3sub(p, f3(P->spot.position))));
+                const float theta = v3dot(l, v3normalize(v3neg(f3(P->spot.direction))));
+                const float delta = P->spot.cos_phi - P->spot.cos_gamma;
+                float intensity = gmin(gmax((theta - P->spot.cos_gamma) / delta, 0.0f), 1.0f);
+                const vec3 amb = v3mul(f3(P->spot.ambient), diffuse);
+                const vec3 dif = v3muls(v3mul(v3muls(f3(P->spot.diffuse), d), diffuse), lit);
+                const vec3 spe = v3muls(v3mul(v3muls(f3(P->spot.specular), s), specular), lit);
+                color = v3add(color, v3muls(v3add(amb, v3muls(v3add(dif, spe), intensity)), att));
+            }
+            const float inv_z = 1.0f / v3length(v3sub(p, eye)), inv_near = 1.0f / P->near_plane, inv_far = 1.0f / P->far_plane;
+            out[0] = color.x; out[1] = color.y; out[2] = color.z;
+            out[3] = (inv_z - inv_near) / (inv_far - inv_near);
+        }
+}

@@ -127,6 +127,19 @@ uint64_t orc_trace_rays(const orc_world *, const float *origins, const float *di
 uint64_t orc_trace_image(const orc_world *, const orc_camera *, const orc_params *,
                          int x0, int y0, int w, int h, orc_hit *out, orc_counters *cnt, int threads);
 
+/* --- shading stage (restatement of shaders/World.Fragment.glsl:63-138,180-197; same layout as svo_shade_params) --- */
+typedef struct orc_material { float ambient[3], diffuse[3], specular[3]; float shininess; } orc_material;
+typedef struct orc_shade_params {
+    struct { float position[3], ambient[3], diffuse[3], specular[3]; float constant, linear, quadratic; } point;
+    struct { float position[3], direction[3], ambient[3], diffuse[3], specular[3]; } directional;
+    struct { float position[3], direction[3], ambient[3], diffuse[3], specular[3];
+             float cos_phi, cos_gamma, constant, linear, quadratic; } spot;
+    orc_material materials[8];
+    float eps, gamma, near_plane, far_plane;
+} orc_shade_params;
+void orc_shade_image(const orc_camera *cam, const orc_shade_params *p, int x0, int y0, int w, int h,
+                     const orc_hit *gbuffer, float *rgba);
+
 #ifdef __cplusplus
 }
 #endif

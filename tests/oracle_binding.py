@@ -94,6 +94,20 @@ lib.orc_trace_image.restype = C.c_uint64
 lib.orc_camera_ray.argtypes = [C.POINTER(OCamera), C.c_int, C.c_int, C.POINTER(Vec3), C.POINTER(Vec3)]
 
 
+lib.orc_shade_image.argtypes = [C.POINTER(OCamera), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+lib.orc_shade_image.restype = None
+
+
+def shade_image(cam, shade_params, rect, gbuffer):
+    """Oracle shading of a G-buffer rectangle; shade_params is the product's ShadeParams (same layout)."""
+    x0, y0, w, h = rect
+    g = np.ascontiguousarray(gbuffer).reshape(h, w)
+    out = np.zeros((h, w, 4), np.float32)
+    ocam = camera_from(cam)
+    lib.orc_shade_image(C.byref(ocam), C.addressof(shade_params), x0, y0, w, h, g.ctypes.data, out.ctypes.data)
+    return out
+
+
 def vec3(v) -> Vec3:
     return Vec3(float(v[0]), float(v[1]), float(v[2]))
 
