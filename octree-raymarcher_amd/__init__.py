@@ -424,7 +424,7 @@ class World:
         return g
 
     def chunkmarch(self, origins, dirs, shadow: bool = False, kernel: int = KERNEL_AUTO, counters: bool = False,
-                   light_dir=(1.0, -1.0, 0.0)):
+                   light_dir=(1.0, -1.0, 0.0), eps: float = 0.0, caps=(0, 0, 0)):
         """chunkmarch over a ray list (src/Traverse.cpp:127-171); returns HIT_DTYPE[n] [+ counters]."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -432,7 +432,8 @@ class World:
         od, dd = DeviceBuffer.from_numpy(o), DeviceBuffer.from_numpy(d)
         out = DeviceBuffer(max(n, 1) * 32)
         cnt = DeviceBuffer(max(n, 1) * 16) if counters else None
-        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, counters_dev=cnt.ptr if cnt else None)
+        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, eps=eps, caps=caps,
+                           counters_dev=cnt.ptr if cnt else None)
         self.trace_rays(od.ptr, dd.ptr, n, prm, out.ptr)
         _check(lib.svo_stream_synchronize(None), "svo_stream_synchronize")
         g = out.to_numpy(HIT_DTYPE, n)

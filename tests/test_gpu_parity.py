@@ -207,3 +207,19 @@ def test_world_update_after_edits(svo, oracle):
     # the edits really changed the picture
     assert (want["material"] == 5).sum() > 0
     W.destroy()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("eps,caps,light", [
+    (1.0 / 4096.0, (0, 0, 0), (1.0, -1.0, 0.0)),          # the GLSL twin's EPS
+    (0.0, (2, 7, 3), (0.3, -0.8, 0.5)),                   # tiny step caps: most rays give up early, exactly like the oracle
+    (1.0 / 1024.0, (3, 1000, 2), (0.0, -1.0, 0.0)),       # vertical light: axis-parallel shadow rays
+])
+def test_custom_eps_caps_and_light(svo, oracle, worlds, kernel, eps, caps, light):
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    rng = np.random.default_rng(21)
+    o, d = random_rays(rng, 12000, lo, hi)
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True, light_dir=light, eps=eps, caps=caps), threads=8)
+    got = W.chunkmarch(o, d, shadow=True, kernel=_kid(svo, kernel), light_dir=light, eps=eps, caps=caps)
+    assert_gbuffer_equal(got, want, f"custom/{kernel}")
+    assert (want["flags"] & 1).sum() > 300
