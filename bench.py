@@ -10,8 +10,9 @@ written to HBM.  World pools are resident in HBM before the timed region starts.
 
 N > 1: the image is partitioned into 8-row bands dealt round-robin to the ranks (rank r traces
 bands r, r+N, ...; every rank holds the whole world), and each frame ends with ONE RCCL gather of
-the per-rank G-buffer bands to rank 0 (total work fixed -> "scaling": "strong").  The gather of
-frame i overlaps the trace of frame i+1 (double-buffered, RCCL's own stream).
+the per-rank G-buffer bands (packed losslessly to 8 B/pixel) to rank 0 (total work fixed ->
+"scaling": "strong").  Frames are in flight on several HIP streams, so the gather of one frame
+overlaps the trace of the next.
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (k_trace_stack) against the
 8 TB/s HBM peak using the ALGORITHMIC bytes of the reference algorithm: per ray
@@ -131,12 +132,18 @@ def main():
         def trace(i):
             world.trace(cam, prm, (0, 0, iw, ih), bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
     else:
+        # N > 1: trace this rank's bands (32-B records), pack them to the lossless 8-B form (t, normal code, material,
+        # flags) and gather THAT to rank 0: a quarter of the xGMI traffic into rank 0's seven links
+        prec = 8
         bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+        pbufs = [torch.empty((nb, BAND, iw, prec), dtype=torch.uint8, device=dev) for _ in range(S)]
         gdev = dev if args.backend == "nccl" else torch.device("cpu")
-        gathered = [[torch.empty(bufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
+        gathered = [[torch.empty(pbufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
 
         def trace(i):
-            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
+            st = streams[i % S].cuda_stream
+            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i % S].data_ptr(), st)
+            svo.gbuffer_pack(bufs[i % S].data_ptr(), pbufs[i % S].data_ptr(), nb * BAND * iw, st)
 
     def frame(i, works, events=None):
         """Issue frame i on its stream: (wait until its G-buffer is free) -> trace -> (RCCL gather to rank 0)."""
@@ -151,10 +158,10 @@ def main():
                 events[i][1].record(st)
             if world_size > 1:
                 if args.backend == "nccl":
-                    works[i % S] = dist.gather(bufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
+                    works[i % S] = dist.gather(pbufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
                 else:                               # rehearsal: staged through the host, synchronous
                     st.synchronize()
-                    dist.gather(bufs[i % S].cpu(), gathered[i % S] if rank == 0 else None, dst=0)
+                    dist.gather(pbufs[i % S].cpu(), gathered[i % S] if rank == 0 else None, dst=0)
 
     def drain(works):
         for k, wk in enumerate(works):
@@ -244,9 +251,11 @@ def main():
         assert frame_full.shape[0] == ih
         # untimed self-check: the gathered, de-interleaved frame equals a single-GPU trace of the whole image
         whole = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
+        whole_packed = torch.empty((ih, iw, prec), dtype=torch.uint8, device=dev)
         world.trace(cam, prm, (0, 0, iw, ih), whole.data_ptr(), stream)
+        svo.gbuffer_pack(whole.data_ptr(), whole_packed.data_ptr(), ih * iw, stream)
         torch.cuda.synchronize()
-        if not torch.equal(whole.cpu(), frame_full.cpu()):
+        if not torch.equal(whole_packed.cpu(), frame_full.cpu()):
             raise SystemExit("bench.py: gathered multi-GPU frame differs from the single-GPU frame")
 
     result = None
@@ -271,7 +280,7 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather",
+                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }

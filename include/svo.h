@@ -239,6 +239,14 @@ int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *p
 int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev, int64_t n,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);
 
+/* ---- packed G-buffer (8 bytes / pixel) for the multi-GPU gather ------------------------------------------
+ * { float t; uint32 w } with w = material (bits 0-15) | flags & 0xFF (bits 16-23) | normal code (bits 24-30):
+ * per axis 2 bits (0: -, 1: 0, 2: +) in bits 24-29, bit 30 = NaN normal.  cubeNormal only ever yields
+ * normalize(ivec3 in {-1,0,1}^3) (shaders/Chunkmarch.glsl:128-136), so t, normal, material and flags survive the
+ * round trip bit for bit; the parity ids (chunk, node, cell) are not carried (unpack zeroes them). */
+int svo_gbuffer_pack(const svo_hit *gbuffer_dev, uint64_t *packed_dev, int64_t n, void *stream);
+int svo_gbuffer_unpack(const uint64_t *packed_dev, svo_hit *gbuffer_dev, int64_t n, void *stream);
+
 /* ---- shading stage: Blinn-Phong x 3 lights over the G-buffer --------------------
  * shaders/World.Fragment.glsl:63-138,180-197.  The reference multiplies the lights with gamma-decoded samples of
  * its Diffuse / Specular texture atlas, which is not part of the repository; here the albedo comes from the

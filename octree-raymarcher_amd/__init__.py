@@ -120,7 +120,7 @@ class WorldInfo(C.Structure):
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
-    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_defaults",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
     "svo_trace", "svo_trace_rows", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -142,6 +142,8 @@ lib.svo_chunk_read.argtypes = [C.c_char_p, C.POINTER(ChunkDesc), C.POINTER(C.c_u
 lib.svo_chunk_free.argtypes = [C.POINTER(ChunkDesc)]
 lib.svo_chunk_free.restype = None
 lib.svo_world_shift.argtypes = [_P, C.POINTER(C.c_int)]
+lib.svo_gbuffer_pack.argtypes = [_P, _P, C.c_int64, _P]
+lib.svo_gbuffer_unpack.argtypes = [_P, _P, C.c_int64, _P]
 lib.svo_shade_defaults.argtypes = [C.POINTER(ShadeParams)]
 lib.svo_shade_defaults.restype = None
 lib.svo_shade.argtypes = [C.POINTER(Camera), C.POINTER(ShadeParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]
@@ -270,6 +272,14 @@ def chunk_read(path: str) -> dict:
                 "treestoragesize": ts.value, "twigstoragesize": ws.value}
     finally:
         lib.svo_chunk_free(C.byref(d))
+
+
+def gbuffer_pack(gbuffer_ptr: int, packed_ptr: int, n: int, stream: int = 0):
+    _check(lib.svo_gbuffer_pack(gbuffer_ptr, packed_ptr, n, stream), "svo_gbuffer_pack")
+
+
+def gbuffer_unpack(packed_ptr: int, gbuffer_ptr: int, n: int, stream: int = 0):
+    _check(lib.svo_gbuffer_unpack(packed_ptr, gbuffer_ptr, n, stream), "svo_gbuffer_unpack")
 
 
 def shade_defaults() -> ShadeParams:

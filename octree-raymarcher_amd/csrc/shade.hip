@@ -93,6 +93,47 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
     A.rgba[k] = make_float4(color.x, color.y, color.z, (inv_z - inv_near) / (inv_far - inv_near));
 }
 
+// ---- packed G-buffer -------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t axis_code(float v) { return v < 0.0f ? 0u : (v > 0.0f ? 2u : 1u); }
+
+__global__ __launch_bounds__(256) void k_gbuffer_pack(const uint4 *in, uint2 *out, int64_t n)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint4 r0 = in[2 * k], r1 = in[2 * k + 1];
+    const float nx = __uint_as_float(r0.y), ny = __uint_as_float(r0.z), nz = __uint_as_float(r0.w);
+    const bool nan = (nx != nx) | (ny != ny) | (nz != nz);
+    const uint32_t code = nan ? (1u << 6) : (axis_code(nx) | (axis_code(ny) << 2) | (axis_code(nz) << 4));
+    uint2 o;
+    o.x = r0.x;
+    o.y = (r1.x & 0xFFFFu) | (((r1.x >> 16) & 0xFFu) << 16) | (code << 24);
+    out[k] = o;
+}
+
+__global__ __launch_bounds__(256) void k_gbuffer_unpack(const uint2 *in, uint4 *out, int64_t n)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint2 p = in[k];
+    const uint32_t code = p.y >> 24, flags = (p.y >> 16) & 0xFFu;
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    if (flags & SVO_HIT_FLAG) {
+        if (code & (1u << 6)) {
+            nx = ny = nz = __uint_as_float(0x7FC00000u);
+        } else {
+            const float ix = (float)((int)(code & 3u) - 1), iy = (float)((int)((code >> 2) & 3u) - 1), iz = (float)((int)((code >> 4) & 3u) - 1);
+            const float dot = ix * ix + iy * iy + iz * iz;       // normalize(ivec3): the same constants as the march kernels
+            const float inv = dot == 1.0f ? 1.0f : dot == 2.0f ? __uint_as_float(0x3F3504F3u) : dot == 3.0f ? __uint_as_float(0x3F13CD3Au) : __uint_as_float(0x7FC00000u);
+            nx = ix * inv; ny = iy * inv; nz = iz * inv;
+        }
+    }
+    uint4 a, b;
+    a.x = p.x; a.y = __float_as_uint(nx); a.z = __float_as_uint(ny); a.w = __float_as_uint(nz);
+    b.x = (p.y & 0xFFFFu) | (flags << 16); b.y = 0u; b.z = 0u; b.w = 0u;
+    out[2 * k] = a;
+    out[2 * k + 1] = b;
+}
+
 } // namespace
 } // namespace svo
 
@@ -130,6 +171,21 @@ void svo_shade_defaults(svo_shade_params *p)
     }
     p->eps = 1.0f / 8192.0f; p->gamma = 2.2f; p->near_plane = 0.125f; p->far_plane = 8192.0f;
 }
+
+static int pack_common(const void *in, void *out, int64_t n, void *stream, bool pack)
+{
+    if (n < 0 || (n > 0 && (!in || !out))) { set_error("svo_gbuffer_pack/unpack: bad argument"); return SVO_ERR_INVALID_ARG; }
+    if (n == 0) return SVO_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (pack) hipLaunchKernelGGL(k_gbuffer_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)in, (uint2 *)out, n);
+    else hipLaunchKernelGGL(k_gbuffer_unpack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint2 *)in, (uint4 *)out, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("svo_gbuffer_pack/unpack: ") + hipGetErrorString(e)); return e == hipErrorNoDevice ? SVO_ERR_NO_DEVICE : SVO_ERR_HIP; }
+    return SVO_OK;
+}
+
+int svo_gbuffer_pack(const svo_hit *gbuffer_dev, uint64_t *packed_dev, int64_t n, void *stream) { return pack_common(gbuffer_dev, packed_dev, n, stream, true); }
+int svo_gbuffer_unpack(const uint64_t *packed_dev, svo_hit *gbuffer_dev, int64_t n, void *stream) { return pack_common(packed_dev, gbuffer_dev, n, stream, false); }
 
 int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
               const svo_hit *gbuffer_dev, float *rgba_dev, void *stream)

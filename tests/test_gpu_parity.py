@@ -223,3 +223,28 @@ def test_custom_eps_caps_and_light(svo, oracle, worlds, kernel, eps, caps, light
     got = W.chunkmarch(o, d, shadow=True, kernel=_kid(svo, kernel), light_dir=light, eps=eps, caps=caps)
     assert_gbuffer_equal(got, want, f"custom/{kernel}")
     assert (want["flags"] & 1).sum() > 300
+
+
+def test_packed_gbuffer_roundtrip(svo, worlds):
+    """svo_gbuffer_pack / unpack: t, normal, material and flags survive the 8-byte form bit for bit (ids are dropped)."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 333, 177)
+    g = W.draw(cam, shadow=True)
+    # add rays that start inside solid (NaN normals) through the list interface
+    rng = np.random.default_rng(4)
+    o = np.stack([rng.random(500) * 256, np.full(500, 1.0), rng.random(500) * 256], axis=1).astype(np.float32)
+    d = np.tile(np.array([[0, 1, 0]], np.float32), (500, 1))
+    g2 = W.chunkmarch(o, d)
+    allg = np.concatenate([g.reshape(-1), g2])
+    n = allg.size
+    a = svo.DeviceBuffer.from_numpy(allg); p = svo.DeviceBuffer(n * 8); b = svo.DeviceBuffer(n * 32)
+    svo.gbuffer_pack(a.ptr, p.ptr, n); svo.gbuffer_unpack(p.ptr, b.ptr, n)
+    svo.lib.svo_stream_synchronize(None)
+    back = b.to_numpy(svo.HIT_DTYPE, n)
+    assert np.array_equal(back["t"].view(np.uint32), allg["t"].view(np.uint32))
+    assert np.array_equal(back["material"], allg["material"]) and np.array_equal(back["flags"], allg["flags"])
+    nb, na = back["normal"], allg["normal"]
+    same = (nb.view(np.uint32) == na.view(np.uint32)) | (np.isnan(nb) & np.isnan(na)) | ((nb == 0) & (na == 0))   # -0 vs +0 components
+    assert np.all(same)
+    assert np.isnan(allg["normal"]).any() and ((allg["flags"] & 4) != 0).any()
+    assert np.all(back["node"] == 0) and np.all(back["cell"] == 0)
