@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path). gloo = rehearsal of the N>1 control flow on a box with "
                          "fewer GPUs than ranks: ranks share devices and the gather is staged through host memory")
+    ap.add_argument("--no-gather", action="store_true", help="diagnostic (N > 1): trace only, skip the per-frame gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
     args = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
             trace(i)
             if events is not None:
                 events[i][1].record(st)
-            if world_size > 1:
+            if world_size > 1 and not args.no_gather:
                 if args.backend == "nccl":
                     works[i % S] = dist.gather(pbufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
                 else:                               # rehearsal: staged through the host, synchronous
@@ -245,7 +246,7 @@ def main():
         st0.synchronize()
         kernel_ms_avg = sum(a.elapsed_time(b) for a, b in sev) / reps
 
-    if rank == 0 and world_size > 1:
+    if rank == 0 and world_size > 1 and not args.no_gather:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
         frame_full = svo.partition.deinterleave(gathered[(args.steps - 1) % S], ih, BAND)
         assert frame_full.shape[0] == ih
@@ -280,7 +281,7 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
+                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "gather": bool(world_size > 1 and not args.no_gather), "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }
