@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -343,8 +344,18 @@ struct DeviceGrower {
 static int positive_mod_b(int n, int m) { return (m + (n % m)) % m; }
 
 // World::init on the device: same result as generate_world() in terrain.cpp.
+static int generate_world_device_impl(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
+                                      std::vector<ChunkPools> &chunks);
+
 int generate_world_device(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
                           std::vector<ChunkPools> &chunks)
+{
+    try { return generate_world_device_impl(device, w, h, d, chunksize, ccm, tp, chunks); }
+    catch (const std::bad_alloc &) { set_error("svo_world_generate (device builder): out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+}
+
+static int generate_world_device_impl(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
+                                      std::vector<ChunkPools> &chunks)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("svo_world_generate: no HIP device for the device builder"); return SVO_ERR_NO_DEVICE; }

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <string>
 
 #ifndef SVO_STACK_REFILL
@@ -116,7 +117,7 @@ int svo_memcpy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy
 int svo_memcpy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SVO_OK; }
 int svo_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SVO_OK; }
 
-int svo_world_upload(svo_world *w, int device)
+static int world_upload_impl(svo_world *w, int device)
 {
     if (!w) return SVO_ERR_INVALID_ARG;
     int ndev = 0;
@@ -181,8 +182,8 @@ int svo_world_upload(svo_world *w, int device)
     return SVO_OK;
 }
 
-int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
-                     uint64_t tree_left, uint64_t tree_right, uint64_t twig_left, uint64_t twig_right, int realloc_)
+static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc,
+                             uint64_t tree_left, uint64_t tree_right, uint64_t twig_left, uint64_t twig_right, int realloc_)
 {
     if (!w || !desc || chunk < 0 || chunk >= (int)w->chunks.size() || !desc->tree || !desc->trees) return SVO_ERR_INVALID_ARG;
     // 1. adopt the edited pools on the host (validated like svo_world_create)
@@ -221,7 +222,7 @@ int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
         const uint64_t tbase = ((w->tree_pool_len + 8) & ~(uint64_t)7) - 1;
         const uint64_t need_t = tree_fits ? 0 : c.tree_capacity, need_b = twig_fits ? 0 : c.twig_capacity;
         if ((!tree_fits && tbase + need_t > w->tree_pool_cap) || (!twig_fits && w->twig_pool_len + need_b > w->twig_pool_cap))
-            return svo_world_upload(w, w->device);
+            return world_upload_impl(w, w->device);
         if (!tree_fits) { e.tree_off = tbase; w->tree_slot[(size_t)chunk] = need_t; w->tree_pool_len = tbase + need_t; }
         if (!twig_fits) { e.twig_off = w->twig_pool_len; w->twig_slot[(size_t)chunk] = need_b; w->twig_pool_len += need_b; }
         table_dirty = true;
@@ -241,6 +242,22 @@ int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
     if (table_dirty) HIP_TRY(hipMemcpy(w->d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
     return SVO_OK;
+}
+
+// nothing throws across the C ABI: host-side allocations of the two entry points above are fenced here
+int svo_world_upload(svo_world *w, int device)
+{
+    try { return world_upload_impl(w, device); }
+    catch (const std::bad_alloc &) { set_error("svo_world_upload: out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+    catch (...) { set_error("svo_world_upload: unexpected exception"); return SVO_ERR_HIP; }
+}
+
+int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
+                     uint64_t tree_left, uint64_t tree_right, uint64_t twig_left, uint64_t twig_right, int realloc_)
+{
+    try { return world_update_impl(w, chunk, desc, tree_left, tree_right, twig_left, twig_right, realloc_); }
+    catch (const std::bad_alloc &) { set_error("svo_world_update: out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+    catch (...) { set_error("svo_world_update: unexpected exception"); return SVO_ERR_HIP; }
 }
 
 // ---------------------------------------------------------------------------------------------
