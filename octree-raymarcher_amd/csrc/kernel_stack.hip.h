@@ -129,8 +129,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     // tested against the box [Blo, Blo+Bsize] and located on a lattice of pitch `res` anchored at Blo.
     // Entering a brick swaps the frame (and parks the tree level's t / counter); leaving swaps it back.
     V3 O = mk(0, 0, 0), Blo = mk(0, 0, 0);
-    float Bsize = 0.0f, res = 1.0f, t = 0.0f;
-    int cnt = 0;
+    float Bsize = 0.0f, res = 1.0f, inv_res = 1.0f, t = 0.0f;
+    int cnt = 0, cap = 0;              // step counter of the level and its limit (A.cap_tree / A.cap_twig)
     float tt_saved = 0.0f;
     int it_saved = 0;
     // chunk
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         O = p; t = 0.0f; cnt = 0;
                         Blo = clo; Bsize = csize;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
+                        inv_res = recip_pow2(res); cap = A.cap_tree;
                         valid = 0;
                         mode = M_TREE;
                     }
@@ -276,14 +277,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // ---- one step of the current level: tree (src/Traverse.cpp:79-111) or brick (:54-70) -----
         if (mode == M_TREE || mode == M_TWIG) {
             const bool twig = mode == M_TWIG;
-            bool leave = cnt >= (twig ? A.cap_twig : A.cap_tree);
+            bool leave = cnt >= cap;
             cnt += leave ? 0 : 1;
             const V3 p = O + beta * t;
             leave |= !inside(p, Blo, Blo + Bsize);
             // lattice coordinates of p inside the box.  Brick: truncation, as the reference (:58).  Tree: the number
             // of cell boundaries <= p; truncation gives exactly that unless the quotient is integral (p on a lattice
             // plane, or rounded onto one), which the rare branch below settles with the reference's own comparison.
-            const float inv_res = recip_pow2(res);
             const float fx = (p.x - Blo.x) * inv_res, fy = (p.y - Blo.y) * inv_res, fz = (p.z - Blo.z) * inv_res;
             int ux = (int)fx, uy = (int)fy, uz = (int)fz;
 #ifdef SVO_STACK_TIMING
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                         Bsize = res * (float)(low + 1);
                         res = Bsize * 0.25f;                        // leafsize = size / 4, exact
+                        inv_res = recip_pow2(res); cap = A.cap_twig;
                         mode = M_TWIG;
                     } else {                                        // BRANCH at the last level: malformed
                         if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     // A ray pinned on a lattice plane creeps: escape ~ 0, t grows by EPS per step (the reference's CPU path has
                     // no BIGEPS guard, shaders/Chunkmarch.glsl:113).  While the next position stays in the cell just located,
                     // the next reference step is fully determined (same node word / same empty brick cell): take it here.
-                    for (int r = 0; e < 2.0f * eps && r < SVO_CREEP_ROUNDS && cnt < (twig ? A.cap_twig : A.cap_tree) && guard < STEP_GUARD; ++r) {
+                    for (int r = 0; e < 2.0f * eps && r < SVO_CREEP_ROUNDS && cnt < cap && guard < STEP_GUARD; ++r) {
                         const V3 q = O + beta * t;
                         if (!inside(q, Blo, Blo + Bsize)) break;
                         const float qx = (q.x - Blo.x) * inv_res, qy = (q.y - Blo.y) * inv_res, qz = (q.z - Blo.z) * inv_res;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     O = alpha + beta * tw;                          // the chunk march's p (src/Traverse.cpp:144,158)
                     Blo = clo; Bsize = csize;
                     res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
+                    inv_res = recip_pow2(res); cap = A.cap_tree;
                     mode = M_TREE;
                 } else {                                            // out of the chunk
                     tw += e;
