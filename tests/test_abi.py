@@ -135,3 +135,23 @@ def test_product_does_not_link_the_oracle(svo):
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_binding" not in text and "svo_oracle" not in text, f"{f} references the oracle"
+
+
+def test_argument_validation_precedes_any_device_work(svo):
+    """Bad arguments are rejected with SVO_ERR_INVALID_ARG before HIP is touched (works without a GPU)."""
+    cam = svo.default_camera(1, 1, 128, 16, 16)
+    P = svo.shade_defaults()
+    with pytest.raises(svo.SvoError) as e:
+        svo.shade(cam, P, (0, 0, 16, 16), 0, 0)                      # null buffers
+    assert e.value.code == -1
+    with pytest.raises(svo.SvoError) as e:
+        svo.gbuffer_pack(0, 0, 10)
+    assert e.value.code == -1
+    svo.gbuffer_pack(0, 0, 0)                                         # n = 0 is a no-op
+    with pytest.raises(svo.SvoError) as e:
+        svo.gbuffer_unpack(0, 0, -1)
+    assert e.value.code == -1
+    # defaults mirror src/Main.cpp:101-131 and the ML table
+    assert tuple(P.point.position) == (50.0, 8.0, 65.0) and abs(P.spot.cos_phi - np.cos(np.radians(25.0))) < 1e-7
+    assert P.materials[4].shininess == 10000.0 and tuple(P.materials[6].specular) == (1.0, 1.0, 1.0)
+    assert P.eps == np.float32(1 / 8192) and P.near_plane == 0.125 and P.far_plane == 8192.0

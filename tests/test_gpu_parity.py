@@ -248,3 +248,24 @@ def test_packed_gbuffer_roundtrip(svo, worlds):
     assert np.all(same)
     assert np.isnan(allg["normal"]).any() and ((allg["flags"] & 4) != 0).any()
     assert np.all(back["node"] == 0) and np.all(back["cell"] == 0)
+
+
+def test_trace_argument_errors(svo, worlds):
+    W, O, lo, hi, _ = worlds["c1_depth8"]
+    cam = svo.default_camera(1, 1, 128, 64, 64)
+    buf = svo.DeviceBuffer(64 * 64 * 32)
+    for rect in [(-1, 0, 8, 8), (0, 0, -8, 8)]:
+        with pytest.raises(svo.SvoError) as e:
+            W.trace(cam, svo.trace_params(), rect, buf.ptr)
+        assert e.value.code == -1
+    with pytest.raises(svo.SvoError) as e:
+        W.trace(cam, svo.trace_params(), (0, 0, 8, 8), 0)             # null output
+    assert e.value.code == -1
+    with pytest.raises(svo.SvoError) as e:
+        W.trace_rows(cam, svo.trace_params(), 0, 0, 4, 8, buf.ptr)    # band_stride 0
+    assert e.value.code == -1
+    with pytest.raises(svo.SvoError) as e:
+        W.trace(cam, svo.trace_params(kernel=7), (0, 0, 8, 8), buf.ptr)
+    assert e.value.code == -1
+    W.trace(cam, svo.trace_params(), (0, 0, 0, 0), buf.ptr)           # empty rectangle: no-op
+    assert W.last_ray_count() == 0
