@@ -123,8 +123,8 @@ __device__ float d_bound(const DevPyramid &P, const float *q, float x, float z, 
     const uint64_t a = (uint64_t)(x * (float)P.size);
     const uint64_t b = (uint64_t)(z * (float)P.size);
     if (lv <= P.levels) {
-        const uint64_t d = 1ull << (P.levels - lv);
-        return q[d_level_offset(lv) + (b / d) * (P.size / d) + a / d] * P.amplitude + P.shift;
+        const uint32_t sh = P.levels - lv;              // d = 2^sh: the reference's divisions by d are shifts
+        return q[d_level_offset(lv) + ((b >> sh) << lv) + (a >> sh)] * P.amplitude + P.shift;
     }
     const float *base = P.lo + d_level_offset(P.levels);
     const uint64_t m = P.size - 1;

@@ -44,20 +44,27 @@ using namespace svo;
 
 namespace svo {
 
-// bit w of mask[b] = (brick b cell w != 0): one wave per brick, one lane per cell.
+// bit w of mask[b] = (brick b cell w != 0).  One thread per 16-byte eighth of a brick (8 cells -> one mask byte):
+// 16 B per lane, fully coalesced reads of the twig pool, byte stores into the little-endian uint64 masks.
 __global__ __launch_bounds__(256) void k_brick_masks(const uint16_t *twig, uint64_t *mask, uint64_t first, uint64_t count)
 {
-    const uint64_t b = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool live = b < first + count;
-    const uint16_t v = live ? twig[b * TWIG_WORDS + (threadIdx.x & 63)] : (uint16_t)0;
-    const unsigned long long m = __ballot(v != 0);
-    if (live && (threadIdx.x & 63) == 0) mask[b] = m;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // eighth-of-brick index
+    if (i >= count * 8) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(twig + first * TWIG_WORDS)[i];
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bits |= ((w[k] & 0xFFFFu) ? 1u : 0u) << (2 * k);
+        bits |= ((w[k] >> 16) ? 1u : 0u) << (2 * k + 1);
+    }
+    reinterpret_cast<uint8_t *>(mask + first)[i] = (uint8_t)bits;
 }
 
 static int launch_masks(svo_world &w, uint64_t first, uint64_t count, hipStream_t s)
 {
     if (!count) return SVO_OK;
-    const uint64_t blocks = (count + 3) / 4;
+    const uint64_t blocks = (count * 8 + 255) / 256;
     if (blocks > 0x7FFFFFFFull) { set_error("brick pool too large for one mask launch"); return SVO_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_brick_masks, dim3((unsigned)blocks), dim3(256), 0, s, w.d_twig, w.d_mask, first, count);
     HIP_TRY(hipGetLastError());
