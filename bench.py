@@ -40,6 +40,7 @@ WORKLOADS = {
     "c3small_1080p_depth10_4x1x4_shadow": (4, 1, 4, 10, 1920, 1080, True),  # quick rehearsal of c3
     "c4_2160p_depth12_4x1x4_shadow": (4, 1, 4, 12, 3840, 2160, True),      # BASELINE configs[3]
     "c5_1080p_depth16_sparse_shadow": (1, 1, 1, 16, 1920, 1080, True),     # BASELINE configs[4]: full depth in a 1-unit band
+    "c3_grazing_1080p_depth12_4x1x4_shadow": (4, 1, 4, 12, 1920, 1080, True),   # SURVEY §8d second camera: inside the world, looking along it
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BAND = 8                       # rows per band == tile height of the stack kernel
@@ -108,6 +109,8 @@ def main():
     t_up = time.time() - t0
     info = world.info
     cam = svo.default_camera(gw, gd, 128, iw, ih)
+    if "grazing" in args.workload:
+        cam = svo.make_camera((250.3, 90.0, 5.0), (0.06, -0.04, 1.0), (0.0, 1.0, 0.0), 60.0, iw, ih)       # long, shallow marches
     if args.workload.startswith("c5_"):
         cam = svo.make_camera((64.2, 150.0, -40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, iw, ih)   # over the refined band
     if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
