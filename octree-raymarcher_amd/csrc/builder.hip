@@ -8,7 +8,7 @@
 //        k_classify (EMPTY / LEAF / TWIG / BRANCH per frontier node, src/Octree.cpp:105-121)
 //        exclusive scans of the BRANCH and TWIG flags (rocPRIM) == the reference queue's append order
 //        k_emit     (node words, the 8 children of every BRANCH into the next frontier, :155-174)
-//        k_bricks   (one wave per brick, one lane per cell, :122-154)
+//        k_bricks_rows (one thread per brick z-row: 4 column lookups, 16 cells, one 32-byte store, :122-154)
 // The water fill (Ocroot::build) appends blocks in depth-first order and stays on the host (74 ms at depth 12).
 //
 // Layout on the device: the pyramid is the same flat array per bound as on the host (level lv at (4^lv-1)/3,
@@ -211,21 +211,37 @@ __global__ __launch_bounds__(256) void k_emit(const Cell *frontier, uint32_t n, 
     tree[e.slot] = w;
 }
 
-// one wave per brick, one lane per cell (index z*16 + y*4 + x): src/Octree.cpp:122-147
-__global__ __launch_bounds__(256) void k_bricks(const Cell *jobs, uint32_t n, GrowArgs G, DevPyramid P, uint16_t *twig)
+// Bricks (src/Octree.cpp:122-147), one thread per (brick, z-row): the row's four column heights are looked up with
+// the reference's float operations (one lookup per column serves its four y-layers, :131-144), then the row's 16
+// cells (index z*16 + y*4 + x) go out as one 32-byte store.  4 threads per brick, 128 B per brick contiguous.
+__global__ __launch_bounds__(256) void k_bricks_rows(const Cell *jobs, uint32_t n, GrowArgs G, DevPyramid P, uint16_t *twig)
 {
-    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t x = lane & 3, y = (lane >> 2) & 3, z = lane >> 4;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 4u) return;
+    const uint32_t j = i >> 2, z = i & 3u;
     const Cell e = jobs[j];
     const float px = (e.x - G.px) / G.size, py = (e.y - G.py) / G.size, pz = (e.z - G.pz) / G.size;
     const float voxel = G.edge / (float)(1 << TWIG_LEVELS);
-    const float dx = ((float)x * voxel) / G.size;
     const float dz = ((float)z * voxel) / G.size;
-    const float h = d_bound(P, P.hi, px + dx, pz + dz, G.level + TWIG_LEVELS);
-    const uint16_t mat = (uint16_t)d_height_material(py);
-    twig[(uint64_t)e.slot * TWIG_WORDS + lane] = (h >= e.y + (float)y * voxel) ? mat : (uint16_t)0;
+    const uint32_t mat = d_height_material(py);
+    float h[4];
+#pragma unroll
+    for (uint32_t x = 0; x < 4; ++x) {
+        const float dx = ((float)x * voxel) / G.size;
+        h[x] = d_bound(P, P.hi, px + dx, pz + dz, G.level + TWIG_LEVELS);
+    }
+    uint32_t w[8];                                   // cells (y, x) of this z-row: index y*4 + x, two per dword
+#pragma unroll
+    for (uint32_t y = 0; y < 4; ++y) {
+        const float floor_y = e.y + (float)y * voxel;
+        const uint32_t c0 = (h[0] >= floor_y) ? mat : 0u, c1 = (h[1] >= floor_y) ? mat : 0u;
+        const uint32_t c2 = (h[2] >= floor_y) ? mat : 0u, c3 = (h[3] >= floor_y) ? mat : 0u;
+        w[2 * y] = c0 | (c1 << 16);
+        w[2 * y + 1] = c2 | (c3 << 16);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(twig + (uint64_t)e.slot * TWIG_WORDS + z * 16);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 template <typename T>
@@ -322,7 +338,7 @@ struct DeviceGrower {
                 (rc = next.reserve(std::max<uint64_t>(8 * nb, 1), false, s)) != SVO_OK || (rc = jobs.reserve(std::max<uint64_t>(nt, 1), false, s)) != SVO_OK) return rc;
             hipLaunchKernelGGL(k_emit, dim3(blocks_for(n, 256)), dim3(256), 0, s, frontier.p, n, half, word.p, branch_rank.p, twig_rank.p,
                                (uint32_t)trees, (uint32_t)twigs, tree.p, next.p, jobs.p);
-            if (nt) hipLaunchKernelGGL(k_bricks, dim3(blocks_for(nt, 4)), dim3(256), 0, s, jobs.p, (uint32_t)nt, G, P, twig.p);
+            if (nt) hipLaunchKernelGGL(k_bricks_rows, dim3(blocks_for(nt * 4, 256)), dim3(256), 0, s, jobs.p, (uint32_t)nt, G, P, twig.p);
             BUILD_TRY(hipGetLastError());
             // capacity bookkeeping exactly as the host builder (src/Octree.cpp:149-150,160-161)
             if (nb) while (trees + 8 * nb >= c.tree_capacity) c.tree_capacity *= 2;
