@@ -30,8 +30,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
  *     asynchronous on that stream, no host synchronisation happens inside svo_trace*;
  *   - one handle may be used by one host thread at a time; different handles are independent;
- *   - up to 64 svo_trace* launches of one world may be in flight at once (on different streams:
- *     frames in flight); each launch owns a private work-cursor slot from a 64-entry ring.
+ *   - svo_trace* launches of one world may overlap on different streams (frames in flight); each
+ *     launch owns a private work-cursor slot from a 64-entry ring, and a launch that comes round
+ *     to a slot still in use is ordered on the device behind that earlier launch.
  *
  * Semantics are those of the reference's CPU march (src/Traverse.cpp): EPS = 1/8192, step caps
  * 1000/1000/1000, closed-box containment, restart-from-root descent.  The extra per-hit outputs

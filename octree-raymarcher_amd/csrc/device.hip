@@ -77,7 +77,9 @@ int release_device(svo_world &w)
         (void)hipSetDevice(w.device);
         (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
         (void)hipFree(w.d_mask); (void)hipFree(w.d_work);
+        for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
     }
+    w.work_event.clear();
     w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_work = nullptr;
     w.device = -1;
     w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear();
@@ -328,8 +330,13 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
     w->work_last = w->work_next;
     w->work_next = (w->work_next + 1) % WORK_SLOTS;
     A.work = w->d_work + 2 * w->work_last;
+    // a slot coming round again must not be reset under a launch that still reads it: order behind that launch
+    if (w->work_event.size() != WORK_SLOTS) w->work_event.assign(WORK_SLOTS, nullptr);
+    hipEvent_t &ev = reinterpret_cast<hipEvent_t &>(w->work_event[w->work_last]);
+    if (ev) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+    else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_TRY(hipMemsetAsync(A.work, 0, 2 * sizeof(unsigned long long), s));
-    if (A.n <= 0) return SVO_OK;
+    if (A.n <= 0) return hipEventRecord(ev, s) == hipSuccess ? SVO_OK : SVO_ERR_HIP;
     if (kernel == SVO_KERNEL_LITERAL) {
         const int64_t blocks = (A.n + 255) / 256;
         if (blocks > 0x7FFFFFFF) { set_error("svo_trace: too many rays for one launch"); return SVO_ERR_UNSUPPORTED; }
@@ -343,6 +350,7 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
         if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev, s));
     return SVO_OK;
 }
 

@@ -26,6 +26,7 @@ struct svo_world {
     uint64_t *d_mask = nullptr;
     unsigned long long *d_work = nullptr;         // WORK_SLOTS x {tile cursor, rays marched}: one slot per launch in flight
     unsigned work_next = 0, work_last = 0;        // ring cursor; slot of the most recent launch
+    std::vector<void *> work_event;               // hipEvent_t per slot, recorded behind the launch that used it
     std::vector<svo::DevChunk> table;             // host mirror of d_chunks
     std::vector<uint64_t> tree_slot, twig_slot;   // capacity of each chunk's slot (nodes / bricks)
     uint64_t tree_pool_len = 0, twig_pool_len = 0;    // elements in use (incl. alignment padding)
@@ -34,7 +35,7 @@ struct svo_world {
 };
 
 namespace svo {
-constexpr unsigned WORK_SLOTS = 64;               // launches of one world that may be in flight at once
+constexpr unsigned WORK_SLOTS = 64;               // launches of one world that overlap freely; the 65th waits (on the device) for the 1st
 void set_error(const std::string &msg);
 int  validate_chunk(const ChunkPools &c, std::string &why);
 bool chunk_is_exact(const ChunkPools &c, int chunksize);

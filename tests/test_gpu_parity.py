@@ -269,3 +269,30 @@ def test_trace_argument_errors(svo, worlds):
     assert e.value.code == -1
     W.trace(cam, svo.trace_params(), (0, 0, 0, 0), buf.ptr)           # empty rectangle: no-op
     assert W.last_ray_count() == 0
+
+
+def test_launch_ring_wraps_without_sync(svo, worlds):
+    """200 unsynchronised launches over 3 streams (the work-cursor ring has 64 slots): every frame complete and equal."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")                 # the runtime the library is already linked against
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 160, 96)
+    ref = W.draw(cam, shadow=True).reshape(-1)
+    streams = []
+    for _ in range(3):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+        streams.append(h.value)
+    bufs = [svo.DeviceBuffer(160 * 96 * 32) for _ in range(200)]
+    prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK)
+    for i, b in enumerate(bufs):
+        W.trace(cam, prm, (0, 0, 160, 96), b.ptr, streams[i % 3])
+    for s in streams:
+        svo.lib.svo_stream_synchronize(s)
+    rays = W.last_ray_count(streams[(len(bufs) - 1) % 3])
+    assert rays == 160 * 96 + int((ref["flags"] & 1).sum())
+    for i in (0, 1, 63, 64, 65, 127, 128, 199):
+        got = bufs[i].to_numpy(svo.HIT_DTYPE, 160 * 96)
+        assert got.tobytes() == ref.tobytes(), f"launch {i} differs"
+    for s in streams:
+        hip.hipStreamDestroy(ctypes.c_void_p(s))
