@@ -93,6 +93,17 @@ __device__ __forceinline__ V3 cube_normal_pow2(V3 s, V3 lo, float size, float ep
     return mk(ix * inv, iy * inv, iz * inv);
 }
 
+// Octree::branch (src/Octree.cpp:55-58) of the cell (ux, uy, uz) at the level whose selector bit is `sh`.
+__device__ __forceinline__ uint32_t child_slot(int ux, int uy, int uz, int sh)
+{
+    const uint32_t bx = __builtin_amdgcn_ubfe((uint32_t)ux, (uint32_t)sh, 1u);
+    const uint32_t by = __builtin_amdgcn_ubfe((uint32_t)uy, (uint32_t)sh, 1u);
+    const uint32_t bz = __builtin_amdgcn_ubfe((uint32_t)uz, (uint32_t)sh, 1u);
+    return ((bz << 1) + by) * 2u + bx;
+}
+// type == BRANCH (binary 10 in the top bits) as one signed comparison
+__device__ __forceinline__ bool is_branch(uint32_t word) { return (int32_t)word < (int32_t)0xC0000000; }
+
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
@@ -307,21 +318,23 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     const int common = levels - (diff ? 32 - __clz((int)diff) : 0);
                     const int usable = common + 1 < valid ? common + 1 : valid;
                     uint32_t node = 0;
-                    int lvl = 0;
+                    int sh = levels - 1;                            // bit of the cell coordinates that selects the child
                     if (usable > 0) {
-                        const int sh = levels - usable;
-                        node = stk[usable - 1][lane] + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
-                        lvl = usable;
+                        sh = levels - usable;
+                        node = stk[usable - 1][lane] + child_slot(ux, uy, uz, sh);
+                        --sh;
                     }
                     uint32_t word = tree[node];
-                    while (node_type(word) == BRANCH && lvl < levels) {
+                    // No level test: svo_world_create / svo_world_update reject a reachable BRANCH below level depth-2
+                    // (validate_chunk), so the walk ends at or above the last level.
+                    while (is_branch(word)) {
                         const uint32_t base = node_offset(word);
-                        stk[lvl][lane] = base;
-                        const int sh = levels - 1 - lvl;
-                        node = base + (uint32_t)(((ux >> sh) & 1) | (((uy >> sh) & 1) << 1) | (((uz >> sh) & 1) << 2));
-                        ++lvl;
+                        stk[levels - 1 - sh][lane] = base;
+                        node = base + child_slot(ux, uy, uz, sh);
+                        --sh;
                         word = tree[node];
                     }
+                    const int lvl = levels - 1 - sh;
                     valid = lvl; pux = ux; puy = uy; puz = uz;
                     low = (1 << (levels - lvl)) - 1;
                     const uint32_t type = node_type(word);
