@@ -45,6 +45,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BAND = 8                       # rows per band == tile height of the stack kernel
 STREAMS_FOR_SHARE = {1: 8, 2: 8, 4: 16, 8: 16}     # frames in flight per rank when a frame is split N ways (measured)
+FRAMES_PER_GATHER = {1: 1, 2: 1, 4: 2, 8: 4}       # N > 1: consecutive frames of one stream share one (larger) gather
 
 
 def main():
@@ -62,6 +63,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path). gloo = rehearsal of the N>1 control flow on a box with "
                          "fewer GPUs than ranks: ranks share devices and the gather is staged through host memory")
+    ap.add_argument("--frames-per-gather", type=int, default=0,
+                    help="N > 1: G consecutive frames are traced on one stream and gathered to rank 0 by one collective "
+                         "(fewer, larger messages; default 1/1/2/4 for N = 1/2/4/8)")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic (N > 1): trace only, skip the per-frame gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
@@ -77,6 +81,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal aid: run the N > 1 control flow (bands, pack, collective, self-check) with a single rank, e.g. to
+    # exercise the RCCL calls on a one-GPU box
+    multi = world_size > 1 or bool(os.environ.get("SVO_BENCH_FORCE_DIST"))
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -85,8 +92,9 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
         else:
@@ -121,51 +129,60 @@ def main():
     S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
+    G = 1
+    if multi:
+        G = args.frames_per_gather if args.frames_per_gather > 0 else FRAMES_PER_GATHER.get(world_size, 4)
 
     nb = svo.partition.bands_per_rank(ih, world_size, BAND)     # bands per rank (last ones may be padding)
     rec = 32
-    if world_size == 1 and args.emulate_share > 1:
+    if not multi and args.emulate_share > 1:
         nb = svo.partition.bands_per_rank(ih, args.emulate_share, BAND)
         bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
 
         def trace(i):
             world.trace_rows(cam, prm, 0, args.emulate_share, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
-    elif world_size == 1:
+    elif not multi:
         bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
 
         def trace(i):
             world.trace(cam, prm, (0, 0, iw, ih), bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
     else:
         # N > 1: trace this rank's bands (32-B records), pack them to the lossless 8-B form (t, normal code, material,
-        # flags) and gather THAT to rank 0: a quarter of the xGMI traffic into rank 0's seven links
+        # flags) and gather THAT to rank 0: a quarter of the xGMI traffic into rank 0's seven links.  G consecutive
+        # frames share a stream, a buffer and ONE gather, so rank 0 sees N-1 messages per G frames.
         prec = 8
-        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
-        pbufs = [torch.empty((nb, BAND, iw, prec), dtype=torch.uint8, device=dev) for _ in range(S)]
+        bufs = [torch.empty((G, nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+        pbufs = [torch.empty((G, nb, BAND, iw, prec), dtype=torch.uint8, device=dev) for _ in range(S)]
         gdev = dev if args.backend == "nccl" else torch.device("cpu")
         gathered = [[torch.empty(pbufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
 
         def trace(i):
-            st = streams[i % S].cuda_stream
-            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[i % S].data_ptr(), st)
-            svo.gbuffer_pack(bufs[i % S].data_ptr(), pbufs[i % S].data_ptr(), nb * BAND * iw, st)
+            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[(i // G) % S][i % G].data_ptr(), streams[(i // G) % S].cuda_stream)
 
-    def frame(i, works, events=None):
-        """Issue frame i on its stream: (wait until its G-buffer is free) -> trace -> (RCCL gather to rank 0)."""
-        st = streams[i % S]
+    def frame(i, works, events=None, last=False):
+        """Issue frame i on its stream: (wait until its G-buffer is free) -> trace -> (every G frames: pack + RCCL gather to rank 0)."""
+        slot, sub = (i // G) % S, i % G
+        st = streams[slot]
         with torch.cuda.stream(st):
-            if world_size > 1 and works[i % S] is not None:
-                works[i % S].wait()                 # the gather that last read this buffer has finished
+            if multi and sub == 0 and works[slot] is not None:
+                works[slot].wait()                  # the gather that last read this buffer has finished
+                works[slot] = None
             if events is not None:
                 events[i][0].record(st)
             trace(i)
             if events is not None:
                 events[i][1].record(st)
-            if world_size > 1 and not args.no_gather:
-                if args.backend == "nccl":
-                    works[i % S] = dist.gather(pbufs[i % S], gathered[i % S] if rank == 0 else None, dst=0, async_op=True)
-                else:                               # rehearsal: staged through the host, synchronous
-                    st.synchronize()
-                    dist.gather(pbufs[i % S].cpu(), gathered[i % S] if rank == 0 else None, dst=0)
+            if multi and (sub == G - 1 or last):
+                k = sub + 1                         # frames in this batch (the region's last batch may be short)
+                svo.gbuffer_pack(bufs[slot].data_ptr(), pbufs[slot].data_ptr(), k * nb * BAND * iw, st.cuda_stream)
+                if not args.no_gather:
+                    src = pbufs[slot][:k]
+                    dst = [g[:k] for g in gathered[slot]] if rank == 0 else None
+                    if args.backend == "nccl":
+                        works[slot] = dist.gather(src, dst, dst=0, async_op=True)
+                    else:                           # rehearsal: staged through the host, synchronous
+                        st.synchronize()
+                        dist.gather(src.cpu(), dst, dst=0)
 
     def drain(works):
         for k, wk in enumerate(works):
@@ -177,7 +194,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -186,14 +203,14 @@ def main():
     rays_local = world.last_ray_count(streams[0].cuda_stream)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
     rays_t = torch.tensor([rays_local], dtype=torch.int64, device=cdev)
-    if world_size > 1:
+    if multi:
         dist.all_reduce(rays_t)
     rays_frame = int(rays_t.item())
 
     # ---- untimed, rank 0 at N=1: algorithmic bytes of this frame from the reference work counters
     algo_bytes = None
     counters_sum = None
-    if world_size == 1 and not args.emulate_share:
+    if not multi and not args.emulate_share:
         cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
         tmp = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
         cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
@@ -212,7 +229,7 @@ def main():
     # ---- warmup
     works = [None] * S
     for i in range(args.warmup):
-        frame(i, works)
+        frame(i, works, last=(i == args.warmup - 1))
     drain(works)
     works = [None] * S
 
@@ -221,11 +238,11 @@ def main():
     sync_all()
     t_start = time.perf_counter()
     for i in range(args.steps):
-        frame(i, works, ev)
+        frame(i, works, ev, last=(i == args.steps - 1))
     drain(works)
     sync_all()
     elapsed = time.perf_counter() - t_start
-    if world_size > 1:
+    if multi:
         et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
@@ -236,7 +253,7 @@ def main():
     # measures co-scheduling (S launches share the SIMDs), so the dominant kernel is also timed back-to-back on ONE
     # stream with HIP events on that stream; rocprofv3 --kernel-trace of `bench.py --streams 1` must agree.
     kernel_ms_avg = kernel_ms_overlapped
-    if world_size == 1 and not args.emulate_share:
+    if not multi and not args.emulate_share:
         reps = max(5, min(args.steps, 20))
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         st0 = streams[0]
@@ -249,9 +266,10 @@ def main():
         st0.synchronize()
         kernel_ms_avg = sum(a.elapsed_time(b) for a, b in sev) / reps
 
-    if rank == 0 and world_size > 1 and not args.no_gather:
+    if rank == 0 and multi and not args.no_gather:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
-        frame_full = svo.partition.deinterleave(gathered[(args.steps - 1) % S], ih, BAND)
+        lastf = args.steps - 1
+        frame_full = svo.partition.deinterleave([g[lastf % G] for g in gathered[(lastf // G) % S]], ih, BAND)
         assert frame_full.shape[0] == ih
         # untimed self-check: the gathered, de-interleaved frame equals a single-GPU trace of the whole image
         whole = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
@@ -284,11 +302,11 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "frames_in_flight": S, "backend": args.backend if world_size > 1 else None, "gather": bool(world_size > 1 and not args.no_gather), "partition": "single" if world_size == 1 else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
+                "kernel": args.kernel, "frames_in_flight": S, "frames_per_gather": G if multi else None, "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather), "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }
-        if world_size == 1 and not args.emulate_share:
+        if not multi and not args.emulate_share:
             achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
@@ -337,7 +355,7 @@ def main():
         print(json.dumps(result), flush=True)
 
     world.destroy()
-    if world_size > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
