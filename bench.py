@@ -123,7 +123,9 @@ def main():
         cam = svo.make_camera((64.2, 150.0, -40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, iw, ih)   # over the refined band
     if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
         cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
-    prm = svo.trace_params(shadow=shadow, kernel=kernel)
+    # a 1/N share of the frame is small: with several frames in flight, waves that keep refilling (>= 4 tiles each) beat
+    # one wave per tile (+6 % at 1/8 share); no effect on a full 1080p frame, which has more tiles than resident waves
+    prm = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)
     # frames in flight: 3 on one GPU; with N ranks every rank's share of a frame shrinks N-fold while its longest
     # ray does not, so proportionally more frames must overlap to keep the SIMDs busy (measured with --emulate-share)
     S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)

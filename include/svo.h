@@ -135,7 +135,10 @@ typedef struct svo_trace_params {
     int32_t  shadow;                /* !=0: one shadow ray per primary hit toward -light_dir */
     float    light_dir[3];          /* directionalLight.direction, default normalize(1,-1,0) (src/Main.cpp:116) */
     int32_t  kernel;                /* SVO_KERNEL_* */
-    int32_t  _pad;
+    int32_t  tiles_per_wave;        /* SVO_KERNEL_STACK launch shape: every persistent wave is handed at least this
+                                       many 8x8-pixel tiles.  0 / 1 = as many waves as there are tiles (up to what the
+                                       device keeps resident): shortest single frame.  4 suits small images with
+                                       several frames in flight (waves keep refilling instead of draining) */
     uint32_t *counters_dev;         /* optional [n][4] u32 per ray: node words, brick cells, chunk
                                        descriptors, tree steps (reference restart-from-root counts);
                                        only honoured by SVO_KERNEL_LITERAL */

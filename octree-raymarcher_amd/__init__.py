@@ -80,7 +80,7 @@ class Camera(C.Structure):
 class TraceParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_chunk_steps", C.c_int32), ("max_tree_steps", C.c_int32),
                 ("max_twig_steps", C.c_int32), ("shadow", C.c_int32), ("light_dir", C.c_float * 3),
-                ("kernel", C.c_int32), ("_pad", C.c_int32), ("counters_dev", C.c_void_p)]
+                ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p)]
 
 
 class Material(C.Structure):
@@ -237,7 +237,7 @@ def default_camera(world_w: int, world_d: int, chunksize: int, width: int, heigh
 
 
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
-                 caps=(0, 0, 0), counters_dev: Optional[int] = None) -> TraceParams:
+                 caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0) -> TraceParams:
     p = TraceParams()
     p.eps = eps
     p.max_chunk_steps, p.max_tree_steps, p.max_twig_steps = caps
@@ -245,6 +245,7 @@ def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0
     p.light_dir[:] = [float(x) for x in light_dir]
     p.kernel = kernel
     p.counters_dev = counters_dev
+    p.tiles_per_wave = tiles_per_wave
     return p
 
 

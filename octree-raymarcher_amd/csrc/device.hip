@@ -87,9 +87,9 @@ int release_device(svo_world &w)
     return SVO_OK;
 }
 
-// Persistent grid = the waves the kernel can keep resident (occupancy query), never more tiles than exist.
+// Persistent grid = the waves the kernel can keep resident (occupancy query), never more than tiles / tiles_per_wave.
 template <int MAXLV>
-static int launch_stack(svo_world *w, const TraceArgs &A, hipStream_t s)
+static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, hipStream_t s)
 {
     auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES>;
     if (w->occupancy_blocks <= 0) {
@@ -99,7 +99,8 @@ static int launch_stack(svo_world *w, const TraceArgs &A, hipStream_t s)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
         w->occupancy_blocks = prop.multiProcessorCount * per_cu;
     }
-    const int blocks = (int)std::min<int64_t>(A.ntiles, w->occupancy_blocks);
+    const int64_t per_wave = tiles_per_wave > 1 ? tiles_per_wave : 1;
+    const int blocks = (int)std::min<int64_t>((A.ntiles + per_wave - 1) / per_wave, w->occupancy_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
     return SVO_OK;
 }
@@ -344,9 +345,10 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
     } else {
         if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
         int rc;
-        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, s);
-        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, s);
-        else rc = launch_stack<16>(w, A, s);
+        const int tpw = prm ? prm->tiles_per_wave : 0;
+        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, tpw, s);
+        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, tpw, s);
+        else rc = launch_stack<16>(w, A, tpw, s);
         if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());

@@ -296,3 +296,15 @@ def test_launch_ring_wraps_without_sync(svo, worlds):
         assert got.tobytes() == ref.tobytes(), f"launch {i} differs"
     for s in streams:
         hip.hipStreamDestroy(ctypes.c_void_p(s))
+
+
+@pytest.mark.parametrize("tpw", [0, 4, 64, 100000])
+def test_tiles_per_wave_is_only_a_launch_shape(svo, worlds, tpw):
+    """svo_trace_params.tiles_per_wave changes how many persistent waves share the tiles, never the records."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 203, 131)
+    ref = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL).reshape(-1)
+    buf = svo.DeviceBuffer(203 * 131 * 32)
+    W.trace(cam, svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tiles_per_wave=tpw), (0, 0, 203, 131), buf.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    assert buf.to_numpy(svo.HIT_DTYPE, 203 * 131).tobytes() == ref.tobytes()
