@@ -286,7 +286,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
 
         // ---- one step of the current level: tree (src/Traverse.cpp:79-111) or brick (:54-70) -----
+        //      First decide what the step does (locate the cell, read its node / mask bit), then apply exactly one of
+        //      the outcomes below as a flat sequence of predicated updates of the lane state.
         if (mode == M_TREE || mode == M_TWIG) {
+            enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
             bool leave = cnt >= cap;
             cnt += leave ? 0 : 1;
@@ -309,8 +312,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
             if (twig) leave |= (ux > 3) | (uy > 3) | (uz > 3);      // isInsideCube(off, 0, 3), :59 (off >= 0 always: p >= Blo)
 
-            bool advance = false;
+            int what = S_LEAVE;
             int low = 0;                                            // the located cell spans (low+1) lattice steps
+            uint32_t payload = 0;                                   // node word (tree) / cell index (brick)
             if (!leave) {
                 if (!twig) {
                     // descend from the deepest cached level whose coordinate prefix is unchanged
@@ -334,75 +338,26 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         --sh;
                         word = tree[node];
                     }
-                    const int lvl = levels - 1 - sh;
-                    valid = lvl; pux = ux; puy = uy; puz = uz;
-                    low = (1 << (levels - lvl)) - 1;
+                    valid = levels - 1 - sh; pux = ux; puy = uy; puz = uz;
+                    low = (1 << (sh + 1)) - 1;                      // the node spans 2^(levels - level) cells
                     const uint32_t type = node_type(word);
-                    if (type == EMPTY) {
-                        advance = true;
-                    } else if (type == LEAF) {
-                        tw = tw + (t - eps);                        // src/Traverse.cpp:93,160
-                        hitc = SVO_CELL_NONE;
-                        mode = M_HIT;
-                    } else if (type == TWIG) {                      // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
-                        bmask = A.mask[twig_off + node_offset(word)];
-                        tt_saved = t; it_saved = cnt;
-                        O = p; t = 0.0f; cnt = 0;
-                        Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
-                        Bsize = res * (float)(low + 1);
-                        res = Bsize * 0.25f;                        // leafsize = size / 4, exact
-                        inv_res = recip_pow2(res); cap = A.cap_twig;
-                        mode = M_TWIG;
-                    } else {                                        // BRANCH at the last level: malformed
-                        if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
-                        else store_miss(A.out, outk, SVO_ERR_FLAG);
-                        mode = M_DONE;
-                    }
+                    what = type == EMPTY ? S_ADVANCE : type == LEAF ? S_HIT_LEAF : S_ENTER;
+                    payload = word;
                 } else {
-                    const uint32_t w = (uint32_t)(uz * 16 + uy * 4 + ux);
-                    if ((bmask >> w) & 1ull) {
-                        float s = t;                                // src/Traverse.cpp:63
-                        s += tt_saved;                              // :101
-                        tw = tw + s;                                // :160
-                        hitc = w;
-                        mode = M_HIT;
-                    } else {
-                        advance = true;
-                    }
+                    payload = (uint32_t)(uz * 16 + uy * 4 + ux);
+                    what = ((bmask >> payload) & 1ull) ? S_HIT_CELL : S_ADVANCE;
                 }
             }
 
             // ---- the one escape evaluation of the step: t += escape + EPS.  advance: out of the located cell from p;
             //      leave: out of the level's own box from its origin (src/Traverse.cpp:104-105 brick, :164-168 chunk)
-            if (advance | leave) {
+            if (what <= S_ADVANCE) {
                 const V3 E_p = leave ? O : p;
                 const V3 E_lo = leave ? Blo : mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                 const float E_size = leave ? Bsize : res * (float)(low + 1);
-                float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
+                const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
                 if (!leave) {
                     t += e;
-#if SVO_CREEP_ROUNDS > 0
-                    // A ray pinned on a lattice plane creeps: escape ~ 0, t grows by EPS per step (the reference's CPU path has
-                    // no BIGEPS guard, shaders/Chunkmarch.glsl:113).  While the next position stays in the cell just located,
-                    // the next reference step is fully determined (same node word / same empty brick cell): take it here.
-                    for (int r = 0; e < 2.0f * eps && r < SVO_CREEP_ROUNDS && cnt < cap && guard < STEP_GUARD; ++r) {
-                        const V3 q = O + beta * t;
-                        if (!inside(q, Blo, Blo + Bsize)) break;
-                        const float qx = (q.x - Blo.x) * inv_res, qy = (q.y - Blo.y) * inv_res, qz = (q.z - Blo.z) * inv_res;
-                        int vx = (int)qx, vy = (int)qy, vz = (int)qz;
-                        if (!twig && ((qx == (float)vx) | (qy == (float)vy) | (qz == (float)vz))) {
-                            const int nmax = (1 << levels) - 1;
-                            vx = vx > nmax ? nmax : vx; vy = vy > nmax ? nmax : vy; vz = vz > nmax ? nmax : vz;
-                            vx -= (Blo.x + (float)vx * res > q.x) ? 1 : 0;
-                            vy -= (Blo.y + (float)vy * res > q.y) ? 1 : 0;
-                            vz -= (Blo.z + (float)vz * res > q.z) ? 1 : 0;
-                        }
-                        if ((((vx ^ ux) | (vy ^ uy) | (vz ^ uz)) & ~low) != 0) break;       // left the cell
-                        cnt++; guard++;
-                        e = escape(q, g, E_lo, E_lo + E_size) + eps;
-                        t += e;
-                    }
-#endif
                 } else if (twig) {                                  // back to the tree level that entered the brick
                     t = tt_saved + e;
                     cnt = it_saved;
@@ -415,6 +370,28 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     tw += e;
                     mode = M_WORLD;
                 }
+            }
+            if (what == S_ENTER) {                                  // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
+                bmask = A.mask[twig_off + node_offset(payload)];
+                tt_saved = t; it_saved = cnt;
+                O = p; t = 0.0f; cnt = 0;
+                Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
+                Bsize = res * (float)(low + 1);
+                res = Bsize * 0.25f;                                // leafsize = size / 4, exact
+                inv_res = recip_pow2(res); cap = A.cap_twig;
+                mode = M_TWIG;
+            }
+            if (what == S_HIT_LEAF) {
+                tw = tw + (t - eps);                                // src/Traverse.cpp:93,160
+                hitc = SVO_CELL_NONE;
+                mode = M_HIT;
+            }
+            if (what == S_HIT_CELL) {
+                float sdist = t;                                    // src/Traverse.cpp:63
+                sdist += tt_saved;                                  // :101
+                tw = tw + sdist;                                    // :160
+                hitc = payload;
+                mode = M_HIT;
             }
         }
 
