@@ -104,6 +104,18 @@ __device__ __forceinline__ uint32_t child_slot(int ux, int uy, int uz, int sh)
 // type == BRANCH (binary 10 in the top bits) as one signed comparison
 __device__ __forceinline__ bool is_branch(uint32_t word) { return (int32_t)word < (int32_t)0xC0000000; }
 
+// The launch arguments as they lie in the kernarg segment, behind a barrier the optimiser cannot see through: a rare
+// block that reads its arguments through this re-loads them with scalar loads where it runs, instead of pinning
+// ~60 SGPRs (camera, world grid) across the march loop, which spilled into VGPR lanes (v_readlane in the hot path).
+__device__ __forceinline__ TraceArgs args_reloaded()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    TraceArgs T;
+    __builtin_memcpy(&T, p, sizeof T);              // only the fields the caller uses survive (scalar loads)
+    return T;
+}
+
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
@@ -171,24 +183,25 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #endif
                 // all 64 lanes generate the tile's rays (src/Traverse.cpp:135-140 included) and park them in LDS
                 {
+                    const TraceArgs T = args_reloaded();
                     const int id = tile_first + lane;
                     bool ok;
                     int k = -1;
                     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-                    if (A.from_camera) {
+                    if (T.from_camera) {
                         const unsigned tile = (unsigned)t32;
-                        const int lx = (int)(tile % (unsigned)A.tiles_per_row) * 8 + (lane & 7);
-                        const int ly = (int)(tile / (unsigned)A.tiles_per_row) * 8 + (lane >> 3);
-                        ok = (lx < A.w) & (ly < A.h);
-                        k = ly * A.w + lx;
+                        const int lx = (int)(tile % (unsigned)T.tiles_per_row) * 8 + (lane & 7);
+                        const int ly = (int)(tile / (unsigned)T.tiles_per_row) * 8 + (lane >> 3);
+                        ok = (lx < T.w) & (ly < T.h);
+                        k = ly * T.w + lx;
                         int px = 0, py = 0;
-                        if (ok) local_to_pixel(A, lx, ly, px, py);
-                        if (ok && (py >= A.imgh || px >= A.imgw)) { store_miss(A.out, k, 0); ok = false; }
-                        if (ok) camera_ray(A, px, py, o, d);
+                        if (ok) local_to_pixel(T, lx, ly, px, py);
+                        if (ok && (py >= T.imgh || px >= T.imgw)) { store_miss(A.out, k, 0); ok = false; }
+                        if (ok) camera_ray(T, px, py, o, d);
                     } else {
-                        ok = id < A.n;
+                        ok = id < T.n;
                         k = id;
-                        if (ok) { o = ld3(A.origins + 3 * (long long)id); d = ld3(A.dirs + 3 * (long long)id); }
+                        if (ok) { o = ld3(T.origins + 3 * (long long)id); d = ld3(T.dirs + 3 * (long long)id); }
                     }
                     const V3 gg = recip(d);
                     float t0 = 0.0f;
