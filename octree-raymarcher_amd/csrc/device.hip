@@ -169,12 +169,12 @@ static int world_upload_impl(svo_world *w, int device)
             hipMalloc((void **)&w->d_twig, w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
             hipMalloc((void **)&w->d_mask, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
             hipMalloc((void **)&w->d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
-            hipMalloc((void **)&w->d_work, WORK_SLOTS * 2 * sizeof(unsigned long long)) != hipSuccess) {
+            hipMalloc((void **)&w->d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
             set_error("svo_world_upload: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break;
         }
         if (hipMemset(w->d_tree, 0, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
             hipMemset(w->d_mask, 0, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
-            hipMemset(w->d_work, 0, WORK_SLOTS * 2 * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
+            hipMemset(w->d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
         for (size_t i = 0; i < n && rc == SVO_OK; ++i) {
             const ChunkPools &c = w->chunks[i];
             const DevChunk &e = w->table[i];
@@ -330,13 +330,13 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
     // every launch gets its own {tile cursor, ray count} slot so that launches on different streams may overlap
     w->work_last = w->work_next;
     w->work_next = (w->work_next + 1) % WORK_SLOTS;
-    A.work = w->d_work + 2 * w->work_last;
+    A.work = w->d_work + WORK_SLOT_WORDS * w->work_last;
     // a slot coming round again must not be reset under a launch that still reads it: order behind that launch
     if (w->work_event.size() != WORK_SLOTS) w->work_event.assign(WORK_SLOTS, nullptr);
     hipEvent_t &ev = reinterpret_cast<hipEvent_t &>(w->work_event[w->work_last]);
     if (ev) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
     else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIP_TRY(hipMemsetAsync(A.work, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(A.work, 0, WORK_SLOT_WORDS * sizeof(unsigned long long), s));
     if (A.n <= 0) return hipEventRecord(ev, s) == hipSuccess ? SVO_OK : SVO_ERR_HIP;
     if (kernel == SVO_KERNEL_LITERAL) {
         const int64_t blocks = (A.n + 255) / 256;
@@ -430,7 +430,7 @@ int svo_trace_last_ray_count(svo_world *w, void *stream, uint64_t *rays)
     HIP_TRY(hipSetDevice(w->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     unsigned long long v[2] = { 0, 0 };
-    HIP_TRY(hipMemcpy(v, w->d_work + 2 * w->work_last, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, w->d_work + WORK_SLOT_WORDS * w->work_last, sizeof v, hipMemcpyDeviceToHost));
     *rays = v[1];
     return SVO_OK;
 }

@@ -4,7 +4,9 @@
 // corners are exact floats (svo_world_info.exact_geometry: power-of-two chunk edge, positions on
 // the voxel lattice), reached differently:
 //
-//  * Persistent single-wave workgroups pull 8x8-pixel tiles (64 rays) from an atomic cursor.
+//  * Persistent single-wave workgroups pull 8x8-pixel tiles (64 rays) from atomic cursors, one per screen region;
+//    a wave starts in the region of its XCD (HW_REG_XCC_ID), so each XCD's L2 serves one part of the world, and
+//    moves on to the other regions when its own is used up.
 //    When >= REFILL lanes of the wave have retired (64-bit __ballot), the dead lanes are handed
 //    the next ray ids by prefix rank (mbcnt) — the wave re-compacts instead of idling on its
 //    slowest ray.  A primary hit turns its lane into the shadow ray in place.
@@ -135,6 +137,16 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const float csize = A.chunksize;
 
     // ---- wave state (uniform) ------------------------------------------------------------
+    // The image is dealt out as TILE_REGIONS screen regions (column strips of 8x8 tiles; row bands when the raster has
+    // fewer than 8 tile columns, e.g. ray lists), each behind its own cursor.  A wave starts in the region of its XCD:
+    // an XCD's waves then march rays that traverse the same part of the world, and that XCD's private L2 holds it.
+    // A wave whose region is used up moves on to the next one (work stealing).
+    const int tr_cols = A.tiles_per_row;
+    const int tr_rows = A.ntiles / (tr_cols > 0 ? tr_cols : 1);
+    const bool by_cols = tr_cols >= TILE_REGIONS;
+    const int reg_q = (by_cols ? tr_cols : tr_rows) / TILE_REGIONS, reg_rem = (by_cols ? tr_cols : tr_rows) % TILE_REGIONS;
+    int region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (TILE_REGIONS - 1));    // HW_REG_XCC_ID[3:0]
+    int regions_left = TILE_REGIONS;
     int tile_first = 0;             // first ray id of the tile being handed out
     int tile_next = 64;             // next unassigned slot of that tile (64 = exhausted)
     bool more = true;               // tiles left in the global cursor
@@ -172,10 +184,24 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         unsigned long long dead = __ballot(mode == M_DONE);
         while (more && __popcll(dead) >= REFILL) {
             if (tile_next >= 64) {
-                unsigned long long tix = 0;
-                if (lane == 0) tix = atomicAdd(&A.work[0], 1ull);
-                const int t32 = __builtin_amdgcn_readfirstlane((int)tix);
-                if (t32 >= A.ntiles) { more = false; break; }
+                int t32 = -1, tcol = 0, trow = 0;               // raster index of the tile, its column and row
+                while (regions_left > 0) {
+                    const int span = reg_q + (region < reg_rem ? 1 : 0);                    // columns (rows) of this region
+                    const int first = region * reg_q + (region < reg_rem ? region : reg_rem);
+                    const int count = span * (by_cols ? tr_rows : tr_cols);
+                    unsigned long long tix = 0;
+                    if (lane == 0) tix = atomicAdd(&A.work[WORK_CURSOR0 + region], 1ull);
+                    const int t = __builtin_amdgcn_readfirstlane((int)tix);
+                    if (t < count) {
+                        if (by_cols) { trow = t / span; tcol = first + (t - trow * span); }
+                        else { trow = first + t / tr_cols; tcol = t % tr_cols; }
+                        t32 = trow * tr_cols + tcol;
+                        break;
+                    }
+                    region = (region + 1) & (TILE_REGIONS - 1);
+                    --regions_left;
+                }
+                if (t32 < 0) { more = false; break; }
                 tile_first = t32 * 64;
                 tile_next = 0;
 #ifdef SVO_STACK_TIMING
@@ -189,9 +215,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     int k = -1;
                     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
                     if (T.from_camera) {
-                        const unsigned tile = (unsigned)t32;
-                        const int lx = (int)(tile % (unsigned)T.tiles_per_row) * 8 + (lane & 7);
-                        const int ly = (int)(tile / (unsigned)T.tiles_per_row) * 8 + (lane >> 3);
+                        const int lx = tcol * 8 + (lane & 7);
+                        const int ly = trow * 8 + (lane >> 3);
                         ok = (lx < T.w) & (ly < T.h);
                         k = ly * T.w + lx;
                         int px = 0, py = 0;

@@ -35,6 +35,12 @@ struct DevChunk {               // 32 bytes
 static_assert(sizeof(DevChunk) == 32, "chunk table entry is 32 bytes");
 
 // Everything a trace kernel needs, passed by value.
+// Launch slot (u64 words).  The stack kernel deals the image out as TILE_REGIONS screen regions, one per XCD (own L2),
+// each with its own cursor; a wave whose region is empty moves on to the next one.
+constexpr int TILE_REGIONS = 8;
+constexpr int WORK_CURSOR0 = 2;
+constexpr int WORK_SLOT_WORDS = 16;     // 128 B: slots do not share a cache line
+
 struct TraceArgs {
     // world (src/Traverse.cpp:129-133: chunkmin/chunkmax of the whole grid)
     float    worldmin[3], worldmax[3];
@@ -64,7 +70,7 @@ struct TraceArgs {
     // outputs
     void     *out;              // svo_hit[n]
     uint32_t *counters;         // optional [n][4]
-    unsigned long long *work;   // [0] tile cursor, [1] rays marched
+    unsigned long long *work;   // launch slot: [1] rays marched, [WORK_CURSOR0 + r] tile cursor of screen region r
     int32_t  ntiles, tiles_per_row;
 };
 
