@@ -311,11 +311,13 @@ def main():
         if not multi and not args.emulate_share:
             achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
             traffic = None
+            valu = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+                    valu = tj.get(args.workload, {}).get("valu_insts_per_launch")
                 except Exception:
                     traffic = None
             result["roofline"] = {
@@ -331,6 +333,12 @@ def main():
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
                 "counters": counters_sum,
             }
+            if valu:
+                # what the march is really bound by: a wave64 VALU instruction holds one of the
+                # 1024 SIMDs for 4 cycles; profiled instruction count per launch over this run's time per frame
+                simd_cycles = 1024 * 2.4e9 * (elapsed / args.steps)
+                result["roofline"]["valu_issue"] = {"insts_per_launch": int(valu), "frac_of_issue_slots": round(valu * 4 / simd_cycles, 4),
+                                                    "note": "SQ_INSTS_VALU from profiles/ (PMC pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x s per frame)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
