@@ -8,11 +8,15 @@ written to HBM.  World pools are resident in HBM before the timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+Frames are pipelined: F consecutive frames (F cameras - here F views of the benchmark camera) are
+marched by ONE launch (svo_trace_frames: the kernel's persistent waves run through all F frames'
+tiles and drain once per launch instead of once per frame), and S such launches are in flight on S
+HIP streams.  K steps = K frames = ceil(K/F) launches (the last one may be short).
+
 N > 1: the image is partitioned into 8-row bands dealt round-robin to the ranks (rank r traces
-bands r, r+N, ...; every rank holds the whole world), and each frame ends with ONE RCCL gather of
-the per-rank G-buffer bands (packed losslessly to 8 B/pixel) to rank 0 (total work fixed ->
-"scaling": "strong").  Frames are in flight on several HIP streams, so the gather of one frame
-overlaps the trace of the next.
+bands r, r+N, ...; every rank holds the whole world), and each launch ends with ONE RCCL gather of
+its F frames' per-rank G-buffer bands (packed losslessly to 8 B/pixel) to rank 0 (total work fixed
+-> "scaling": "strong"); the gather of one launch overlaps the trace of the next.
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (k_trace_stack) against the
 8 TB/s HBM peak using the ALGORITHMIC bytes of the reference algorithm: per ray
@@ -44,8 +48,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BAND = 8                       # rows per band == tile height of the stack kernel
-STREAMS_FOR_SHARE = {1: 8, 2: 8, 4: 16, 8: 16}     # frames in flight per rank when a frame is split N ways (measured)
-FRAMES_PER_GATHER = {1: 1, 2: 1, 4: 2, 8: 4}       # N > 1: consecutive frames of one stream share one (larger) gather
+STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 8}       # launches in flight per rank when a frame is split N ways (measured)
+FRAMES_PER_LAUNCH = {1: 4, 2: 8, 4: 8, 8: 8}       # consecutive frames marched by one launch (and shipped by one gather)
 
 
 def main():
@@ -63,9 +67,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path). gloo = rehearsal of the N>1 control flow on a box with "
                          "fewer GPUs than ranks: ranks share devices and the gather is staged through host memory")
-    ap.add_argument("--frames-per-gather", type=int, default=0,
-                    help="N > 1: G consecutive frames are traced on one stream and gathered to rank 0 by one collective "
-                         "(fewer, larger messages; default 1/1/2/4 for N = 1/2/4/8)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="F consecutive frames are marched by ONE launch (svo_trace_frames; at N > 1 also gathered to rank 0 "
+                         "by one collective): the persistent waves drain once per launch.  1 = one launch per frame")
+    ap.add_argument("--frames-per-gather", type=int, default=0, help="older name of --frames-per-launch at N > 1")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic (N > 1): trace only, skip the per-frame gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
@@ -126,56 +131,68 @@ def main():
     # a 1/N share of the frame is small: with several frames in flight, waves that keep refilling (>= 4 tiles each) beat
     # one wave per tile (+6 % at 1/8 share); no effect on a full 1080p frame, which has more tiles than resident waves
     prm = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)
-    # frames in flight: 3 on one GPU; with N ranks every rank's share of a frame shrinks N-fold while its longest
-    # ray does not, so proportionally more frames must overlap to keep the SIMDs busy (measured with --emulate-share)
+    # launches in flight: a launch's critical path is its longest ray, so its tail leaves SIMDs idle that the next
+    # launches' bulk fills; with N ranks a rank's share of a frame shrinks N-fold, so more frames ride in one launch
+    # (both tables measured with --emulate-share)
     S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
-    G = 1
-    if multi:
-        G = args.frames_per_gather if args.frames_per_gather > 0 else FRAMES_PER_GATHER.get(world_size, 4)
+    # F consecutive frames form one group: ONE launch marches them (svo_trace_frames: the persistent waves drain once
+    # per launch, not once per frame) and, at N > 1, ONE gather ships them.  Group j runs on stream j % S.
+    if args.frames_per_launch > 0:
+        G = args.frames_per_launch
+    elif multi and args.frames_per_gather > 0:
+        G = args.frames_per_gather
+    else:
+        G = FRAMES_PER_LAUNCH.get(max(world_size, args.emulate_share, 1), 4)
+    G = max(1, min(G, svo.MAX_FRAMES))
 
     nb = svo.partition.bands_per_rank(ih, world_size, BAND)     # bands per rank (last ones may be padding)
     rec = 32
-    if not multi and args.emulate_share > 1:
-        nb = svo.partition.bands_per_rank(ih, args.emulate_share, BAND)
-        bufs = [torch.empty((nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
-
-        def trace(i):
-            world.trace_rows(cam, prm, 0, args.emulate_share, nb, BAND, bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
-    elif not multi:
-        bufs = [torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
-
-        def trace(i):
-            world.trace(cam, prm, (0, 0, iw, ih), bufs[i % S].data_ptr(), streams[i % S].cuda_stream)
-    else:
-        # N > 1: trace this rank's bands (32-B records), pack them to the lossless 8-B form (t, normal code, material,
-        # flags) and gather THAT to rank 0: a quarter of the xGMI traffic into rank 0's seven links.  G consecutive
-        # frames share a stream, a buffer and ONE gather, so rank 0 sees N-1 messages per G frames.
-        prec = 8
+    prec = 8
+    share = args.emulate_share if (not multi and args.emulate_share > 1) else 0
+    if share:
+        nb = svo.partition.bands_per_rank(ih, share, BAND)
+    if multi or share:
         bufs = [torch.empty((G, nb, BAND, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+    else:
+        bufs = [torch.empty((G, ih, iw, rec), dtype=torch.uint8, device=dev) for _ in range(S)]
+    if multi:
+        # N > 1: this rank's bands (32-B records) are packed to the lossless 8-B form (t, normal code, material, flags)
+        # and THAT is gathered to rank 0: a quarter of the xGMI traffic into rank 0's seven links
         pbufs = [torch.empty((G, nb, BAND, iw, prec), dtype=torch.uint8, device=dev) for _ in range(S)]
         gdev = dev if args.backend == "nccl" else torch.device("cpu")
         gathered = [[torch.empty(pbufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
 
-        def trace(i):
-            world.trace_rows(cam, prm, rank, world_size, nb, BAND, bufs[(i // G) % S][i % G].data_ptr(), streams[(i // G) % S].cuda_stream)
+    def trace_group(slot, k):
+        """One launch: k <= G frames (here: k views of the same camera) into bufs[slot][:k] on stream `slot`."""
+        st = streams[slot].cuda_stream
+        cams = [cam] * k
+        if multi:
+            world.trace_rows_frames(cams, prm, rank, world_size, nb, BAND, bufs[slot].data_ptr(), st)
+        elif share:
+            world.trace_rows_frames(cams, prm, 0, share, nb, BAND, bufs[slot].data_ptr(), st)
+        else:
+            world.trace_frames(cams, prm, (0, 0, iw, ih), bufs[slot].data_ptr(), st)
 
     def frame(i, works, events=None, last=False):
-        """Issue frame i on its stream: (wait until its G-buffer is free) -> trace -> (every G frames: pack + RCCL gather to rank 0)."""
+        """Frame i joins its group; the group's last frame issues the launch (and, at N > 1, pack + gather to rank 0)."""
         slot, sub = (i // G) % S, i % G
+        if not (sub == G - 1 or last):
+            return
+        k = sub + 1                                 # frames in this group (the region's last group may be short)
         st = streams[slot]
         with torch.cuda.stream(st):
-            if multi and sub == 0 and works[slot] is not None:
+            if multi and works[slot] is not None:
                 works[slot].wait()                  # the gather that last read this buffer has finished
                 works[slot] = None
             if events is not None:
-                events[i][0].record(st)
-            trace(i)
+                events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), k))
+                events[-1][0].record(st)
+            trace_group(slot, k)
             if events is not None:
-                events[i][1].record(st)
-            if multi and (sub == G - 1 or last):
-                k = sub + 1                         # frames in this batch (the region's last batch may be short)
+                events[-1][1].record(st)
+            if multi:
                 svo.gbuffer_pack(bufs[slot].data_ptr(), pbufs[slot].data_ptr(), k * nb * BAND * iw, st.cuda_stream)
                 if not args.no_gather:
                     src = pbufs[slot][:k]
@@ -201,7 +218,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---- untimed: ray count of one frame (primary + shadow), all ranks
-    trace(0)
+    trace_group(0, 1)
     rays_local = world.last_ray_count(streams[0].cuda_stream)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
     rays_t = torch.tensor([rays_local], dtype=torch.int64, device=cdev)
@@ -222,9 +239,9 @@ def main():
         counters_sum = dict(node_words=csum[0], brick_cells=csum[1], chunk_descs=csum[2], tree_steps=csum[3])
         algo_bytes = 4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih
         # the fast kernel must have produced the same G-buffer as the literal one (cheap self-check, untimed)
-        trace(0)
+        trace_group(0, 1)
         torch.cuda.synchronize()
-        if not torch.equal(tmp, bufs[0]):
+        if not torch.equal(tmp, bufs[0][0]):
             raise SystemExit("bench.py: stack and literal kernels disagree on the benchmark frame")
         del tmp, cnt
 
@@ -236,7 +253,7 @@ def main():
     works = [None] * S
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = []                                     # (start, end, frames) per launch
     sync_all()
     t_start = time.perf_counter()
     for i in range(args.steps):
@@ -248,22 +265,24 @@ def main():
         et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    kernel_ms_overlapped = sum(kernel_ms) / len(kernel_ms)      # per launch while S frames share the GPU
+    assert sum(k for _, _, k in ev) == args.steps
+    kernel_ms = [a.elapsed_time(b) for a, b, _ in ev]
+    kernel_ms_overlapped = sum(kernel_ms) / len(kernel_ms)      # per launch while S launches share the GPU
 
-    # ---- roofline leg (N=1): the kernel's own launch duration.  With frames in flight the per-launch time above
-    # measures co-scheduling (S launches share the SIMDs), so the dominant kernel is also timed back-to-back on ONE
-    # stream with HIP events on that stream; rocprofv3 --kernel-trace of `bench.py --streams 1` must agree.
+    # ---- roofline leg (N=1): the kernel's own launch duration.  With launches in flight the per-launch time above
+    # measures co-scheduling (S launches share the SIMDs), so the dominant kernel - one launch of G frames, as in the
+    # timed region - is also timed back-to-back on ONE stream with HIP events on that stream; rocprofv3 --kernel-trace
+    # of `bench.py --streams 1` must agree.
     kernel_ms_avg = kernel_ms_overlapped
     if not multi and not args.emulate_share:
-        reps = max(5, min(args.steps, 20))
+        reps = max(5, min(args.steps // G, 20))
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         st0 = streams[0]
         torch.cuda.synchronize()
         with torch.cuda.stream(st0):
             for a, b in sev:
                 a.record(st0)
-                world.trace(cam, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames([cam] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 b.record(st0)
         st0.synchronize()
         kernel_ms_avg = sum(a.elapsed_time(b) for a, b in sev) / reps
@@ -304,20 +323,21 @@ def main():
                 "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "frames_in_flight": S, "frames_per_gather": G if multi else None, "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather), "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
+                "kernel": args.kernel, "launches_in_flight": S, "frames_per_launch": G, "frames_in_flight": S * G, "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather), "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
             },
         }
         if not multi and not args.emulate_share:
-            achieved = algo_bytes / (kernel_ms_avg * 1e-3) / 1e9
+            achieved = algo_bytes * G / (kernel_ms_avg * 1e-3) / 1e9      # one launch marches G frames
             traffic = None
             valu = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
-                    valu = tj.get(args.workload, {}).get("valu_insts_per_launch")
+                    traffic = tj.get(args.workload, {}).get("hbm_bytes_per_frame")      # PMC passes run one frame per launch
+                    traffic = traffic * G if traffic else None
+                    valu = tj.get(args.workload, {}).get("valu_insts_per_frame")
                 except Exception:
                     traffic = None
             result["roofline"] = {
@@ -327,7 +347,7 @@ def main():
                 # the same bytes over whole-job time: what the overlapped launches deliver together
                 "achieved_throughput": round(algo_bytes * args.steps / elapsed / 1e9, 2),
                 "frac_throughput": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "algorithmic_bytes_per_launch": int(algo_bytes) * G, "frames_per_launch": G,
                 "bytes_per_ray": round(algo_bytes / rays_frame, 2),
                 "kernel_ms_avg": round(kernel_ms_avg, 5),
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
@@ -337,8 +357,8 @@ def main():
                 # what the march is really bound by: a wave64 VALU instruction holds one of the
                 # 1024 SIMDs for 4 cycles; profiled instruction count per launch over this run's time per frame
                 simd_cycles = 1024 * 2.4e9 * (elapsed / args.steps)
-                result["roofline"]["valu_issue"] = {"insts_per_launch": int(valu), "frac_of_issue_slots": round(valu * 4 / simd_cycles, 4),
-                                                    "note": "SQ_INSTS_VALU from profiles/ (PMC pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x s per frame)"}
+                result["roofline"]["valu_issue"] = {"insts_per_frame": int(valu), "frac_of_issue_slots": round(valu * 4 / simd_cycles, 4),
+                                                    "note": "SQ_INSTS_VALU per one-frame launch from profiles/ (PMC pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x s per frame)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
@@ -358,7 +378,8 @@ def main():
                               f"{O.last_rays} rays incl. shadow, {dt:.2f} s wall on {cores} threads, oracle/svo_oracle.c -O2",
                 }
                 # parity of the timed product output against the oracle on that sample
-                got = bufs[(args.steps - 1) % S].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+                lastf = args.steps - 1
+                got = bufs[(lastf // G) % S][lastf % G].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
                 same = all(np.array_equal(got[f], ref[f]) for f in ("flags", "material", "chunk", "node", "cell")) and \
                     np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
                 result["cpu_baseline"]["parity_with_gpu"] = bool(same)

@@ -239,6 +239,18 @@ int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *p
                    int band0, int band_stride, int nbands, int band_height,
                    svo_hit *out_dev, void *stream);
 
+/* Several frames in ONE launch: nframes (1..SVO_MAX_FRAMES) cameras of one image size, the same rectangle / bands of
+ * each; frame f's records follow frame f-1's in out_dev (nframes consecutive rasters).  Results are those of nframes
+ * separate svo_trace / svo_trace_rows calls.  What it buys: the stack kernel's persistent waves run through all the
+ * frames' tiles behind one set of cursors, so they drain once per launch instead of once per frame (stereo pairs,
+ * cube-map faces, shadow cascades, several viewports, or simply the next frames of a pipelined renderer). */
+#define SVO_MAX_FRAMES 8
+int svo_trace_frames(svo_world *, const svo_camera *cams, int nframes, const svo_trace_params *params,
+                     int x0, int y0, int w, int h, svo_hit *out_dev, void *stream);
+int svo_trace_rows_frames(svo_world *, const svo_camera *cams, int nframes, const svo_trace_params *params,
+                          int band0, int band_stride, int nbands, int band_height,
+                          svo_hit *out_dev, void *stream);
+
 /* chunkmarch over an explicit list: origins_dev/dirs_dev are [n][3] float on the device. */
 int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev, int64_t n,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);

@@ -117,11 +117,13 @@ class WorldInfo(C.Structure):
 
 
 # every symbol include/svo.h declares (tests check that the library exports exactly these)
+MAX_FRAMES = 8                      # SVO_MAX_FRAMES
+
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
     "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
-    "svo_trace", "svo_trace_rows", "svo_trace_rays", "svo_trace_last_ray_count",
+    "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
 ]
@@ -151,6 +153,8 @@ lib.svo_world_upload.argtypes = [_P, C.c_int]
 lib.svo_world_update.argtypes = [_P, C.c_int, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
 lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
 lib.svo_trace_rows.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
+lib.svo_trace_frames.argtypes = [_P, C.POINTER(Camera), C.c_int, C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
+lib.svo_trace_rows_frames.argtypes = [_P, C.POINTER(Camera), C.c_int, C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
 lib.svo_trace_rays.argtypes = [_P, _P, _P, C.c_int64, C.POINTER(TraceParams), _P, _P]
 lib.svo_trace_last_ray_count.argtypes = [_P, _P, C.POINTER(C.c_uint64)]
 lib.svo_device_count.restype = C.c_int
@@ -407,6 +411,18 @@ class World:
                    out_ptr: int, stream: int = 0):
         _check(lib.svo_trace_rows(self._h, C.byref(cam), C.byref(params), band0, band_stride, nbands, band_height,
                                   out_ptr, stream), "svo_trace_rows")
+
+    def trace_frames(self, cams, params: TraceParams, rect, out_ptr: int, stream: int = 0):
+        """svo_trace_frames: len(cams) frames (<= MAX_FRAMES, one image size) in one launch; out holds the rasters back to back."""
+        x0, y0, w, h = rect
+        arr = (Camera * len(cams))(*cams)
+        _check(lib.svo_trace_frames(self._h, arr, len(cams), C.byref(params), x0, y0, w, h, out_ptr, stream), "svo_trace_frames")
+
+    def trace_rows_frames(self, cams, params: TraceParams, band0: int, band_stride: int, nbands: int, band_height: int,
+                          out_ptr: int, stream: int = 0):
+        arr = (Camera * len(cams))(*cams)
+        _check(lib.svo_trace_rows_frames(self._h, arr, len(cams), C.byref(params), band0, band_stride, nbands, band_height,
+                                         out_ptr, stream), "svo_trace_rows_frames")
 
     def trace_rays(self, origins_ptr: int, dirs_ptr: int, n: int, params: TraceParams, out_ptr: int, stream: int = 0):
         _check(lib.svo_trace_rays(self._h, origins_ptr, dirs_ptr, n, C.byref(params), out_ptr, stream), "svo_trace_rays")

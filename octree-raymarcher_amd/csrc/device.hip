@@ -100,7 +100,8 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, hi
         w->occupancy_blocks = prop.multiProcessorCount * per_cu;
     }
     const int64_t per_wave = tiles_per_wave > 1 ? tiles_per_wave : 1;
-    const int blocks = (int)std::min<int64_t>((A.ntiles + per_wave - 1) / per_wave, w->occupancy_blocks);
+    const int64_t tiles = (int64_t)A.ntiles * (A.nframes > 0 ? A.nframes : 1);
+    const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, w->occupancy_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
     return SVO_OK;
 }
@@ -356,53 +357,88 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
     return SVO_OK;
 }
 
-static int fill_camera(const svo_camera *cam, TraceArgs &A)
+static int fill_cameras(const svo_camera *cams, int nframes, TraceArgs &A)
 {
-    if (!cam || cam->width <= 0 || cam->height <= 0) { set_error("svo_trace: bad camera"); return SVO_ERR_INVALID_ARG; }
+    if (!cams || nframes < 1 || nframes > MAX_FRAMES) { set_error("svo_trace: between 1 and 8 cameras per launch"); return SVO_ERR_INVALID_ARG; }
+    for (int f = 0; f < nframes; ++f) {
+        const svo_camera &c = cams[f];
+        if (c.width <= 0 || c.height <= 0) { set_error("svo_trace: bad camera"); return SVO_ERR_INVALID_ARG; }
+        if (c.width != cams[0].width || c.height != cams[0].height) { set_error("svo_trace_frames: the cameras of one launch share one image size"); return SVO_ERR_INVALID_ARG; }
+        FrameCam &d = A.cams[f];
+        std::memcpy(d.eye, c.eye, sizeof d.eye); std::memcpy(d.fwd, c.forward, sizeof d.fwd);
+        std::memcpy(d.right, c.right, sizeof d.right); std::memcpy(d.up, c.up, sizeof d.up);
+        d.tanx = c.tan_half_x; d.tany = c.tan_half_y;
+    }
     A.from_camera = 1;
-    std::memcpy(A.eye, cam->eye, sizeof A.eye); std::memcpy(A.fwd, cam->forward, sizeof A.fwd);
-    std::memcpy(A.right, cam->right, sizeof A.right); std::memcpy(A.up, cam->up, sizeof A.up);
-    A.tanx = cam->tan_half_x; A.tany = cam->tan_half_y;
-    A.imgw = cam->width; A.imgh = cam->height;
+    A.nframes = nframes;
+    A.imgw = cams[0].width; A.imgh = cams[0].height;
     return SVO_OK;
+}
+
+// Camera-mode launch of A.nframes frames.  The stack kernel marches them behind one set of cursors (its persistent
+// waves drain once per launch, not once per frame); any other kernel gets one launch per frame.
+static int launch_frames(svo_world *w, const svo_trace_params *prm, TraceArgs &A, const char *who, hipStream_t s)
+{
+    A.n = (int64_t)A.w * A.h;
+    A.tiles_per_row = (A.w + 7) / 8;
+    const int64_t tiles = (int64_t)A.tiles_per_row * ((A.h + 7) / 8);
+    if (tiles * A.nframes > 0x3FFFFFFF || A.n * A.nframes > 0x7FFFFFFF) { set_error(std::string(who) + ": image too large"); return SVO_ERR_UNSUPPORTED; }
+    A.ntiles = (int32_t)tiles;
+    if (A.nframes == 1) return launch(w, prm, A, s);
+    const int kernel = pick_kernel(w, prm, A);
+    if (kernel < 0) return kernel;
+    if (kernel == SVO_KERNEL_STACK) return launch(w, prm, A, s);
+    if (prm && prm->counters_dev) { set_error(std::string(who) + ": work counters are per launch of one frame"); return SVO_ERR_UNSUPPORTED; }
+    const int nframes = A.nframes;
+    char *out = static_cast<char *>(A.out);
+    for (int f = 0; f < nframes; ++f) {
+        TraceArgs F = A;
+        F.nframes = 1; F.cams[0] = A.cams[f];
+        F.out = out + (size_t)f * (size_t)A.n * sizeof(svo_hit);
+        const int rc = launch(w, prm, F, s);
+        if (rc != SVO_OK) return rc;
+    }
+    return SVO_OK;
+}
+
+int svo_trace_frames(svo_world *w, const svo_camera *cams, int nframes, const svo_trace_params *prm,
+                     int x0, int y0, int rw, int rh, svo_hit *out_dev, void *stream)
+{
+    TraceArgs A;
+    int rc = fill_common(w, prm, A);
+    if (rc != SVO_OK) return rc;
+    if ((rc = fill_cameras(cams, nframes, A)) != SVO_OK) return rc;
+    if (!out_dev || rw < 0 || rh < 0 || x0 < 0 || y0 < 0) { set_error("svo_trace: bad rectangle or output"); return SVO_ERR_INVALID_ARG; }
+    A.x0 = x0; A.y0 = y0; A.w = rw; A.h = rh;
+    A.bh = rh > 0 ? rh : 1; A.ystep = 0;
+    A.out = out_dev;
+    return launch_frames(w, prm, A, "svo_trace", (hipStream_t)stream);
 }
 
 int svo_trace(svo_world *w, const svo_camera *cam, const svo_trace_params *prm,
               int x0, int y0, int rw, int rh, svo_hit *out_dev, void *stream)
 {
+    return svo_trace_frames(w, cam, 1, prm, x0, y0, rw, rh, out_dev, stream);
+}
+
+int svo_trace_rows_frames(svo_world *w, const svo_camera *cams, int nframes, const svo_trace_params *prm,
+                          int band0, int band_stride, int nbands, int band_height, svo_hit *out_dev, void *stream)
+{
     TraceArgs A;
     int rc = fill_common(w, prm, A);
     if (rc != SVO_OK) return rc;
-    if ((rc = fill_camera(cam, A)) != SVO_OK) return rc;
-    if (!out_dev || rw < 0 || rh < 0 || x0 < 0 || y0 < 0) { set_error("svo_trace: bad rectangle or output"); return SVO_ERR_INVALID_ARG; }
-    A.x0 = x0; A.y0 = y0; A.w = rw; A.h = rh;
-    A.bh = rh > 0 ? rh : 1; A.ystep = 0;
-    A.n = (int64_t)rw * rh;
-    A.tiles_per_row = (rw + 7) / 8;
-    const int64_t tiles = (int64_t)A.tiles_per_row * ((rh + 7) / 8);
-    if (tiles > 0x3FFFFFFF) { set_error("svo_trace: image too large"); return SVO_ERR_UNSUPPORTED; }
-    A.ntiles = (int32_t)tiles;
+    if ((rc = fill_cameras(cams, nframes, A)) != SVO_OK) return rc;
+    if (!out_dev || band0 < 0 || band_stride <= 0 || nbands < 0 || band_height <= 0) { set_error("svo_trace_rows: bad band partition"); return SVO_ERR_INVALID_ARG; }
+    A.x0 = 0; A.y0 = band0 * band_height; A.w = cams[0].width; A.h = nbands * band_height;
+    A.bh = band_height; A.ystep = band_stride * band_height;
     A.out = out_dev;
-    return launch(w, prm, A, (hipStream_t)stream);
+    return launch_frames(w, prm, A, "svo_trace_rows", (hipStream_t)stream);
 }
 
 int svo_trace_rows(svo_world *w, const svo_camera *cam, const svo_trace_params *prm,
                    int band0, int band_stride, int nbands, int band_height, svo_hit *out_dev, void *stream)
 {
-    TraceArgs A;
-    int rc = fill_common(w, prm, A);
-    if (rc != SVO_OK) return rc;
-    if ((rc = fill_camera(cam, A)) != SVO_OK) return rc;
-    if (!out_dev || band0 < 0 || band_stride <= 0 || nbands < 0 || band_height <= 0) { set_error("svo_trace_rows: bad band partition"); return SVO_ERR_INVALID_ARG; }
-    A.x0 = 0; A.y0 = band0 * band_height; A.w = cam->width; A.h = nbands * band_height;
-    A.bh = band_height; A.ystep = band_stride * band_height;
-    A.n = (int64_t)A.w * A.h;
-    A.tiles_per_row = (A.w + 7) / 8;
-    const int64_t tiles = (int64_t)A.tiles_per_row * ((A.h + 7) / 8);
-    if (tiles > 0x3FFFFFFF) { set_error("svo_trace_rows: image too large"); return SVO_ERR_UNSUPPORTED; }
-    A.ntiles = (int32_t)tiles;
-    A.out = out_dev;
-    return launch(w, prm, A, (hipStream_t)stream);
+    return svo_trace_rows_frames(w, cam, 1, prm, band0, band_stride, nbands, band_height, out_dev, stream);
 }
 
 int svo_trace_rays(svo_world *w, const float *origins_dev, const float *dirs_dev, int64_t n,
@@ -412,7 +448,7 @@ int svo_trace_rays(svo_world *w, const float *origins_dev, const float *dirs_dev
     int rc = fill_common(w, prm, A);
     if (rc != SVO_OK) return rc;
     if (n < 0 || (n > 0 && (!origins_dev || !dirs_dev || !out_dev))) { set_error("svo_trace_rays: bad ray list"); return SVO_ERR_INVALID_ARG; }
-    A.from_camera = 0;
+    A.from_camera = 0; A.nframes = 1;
     A.origins = origins_dev; A.dirs = dirs_dev;
     A.n = n;
     A.w = 64; A.h = 1; A.bh = 1; A.tiles_per_row = 1;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_trace_literal(TraceArgs A)
             int px, py;
             local_to_pixel(A, (int)(k % A.w), (int)(k / A.w), px, py);
             if (py >= A.imgh || px >= A.imgw) { store_miss(A.out, k, 0); live = false; }
-            else camera_ray(A, px, py, o, d);
+            else camera_ray(A.cams[0], A.imgw, A.imgh, px, py, o, d);
         } else {
             o = ld3(A.origins + 3 * k);
             d = ld3(A.dirs + 3 * k);

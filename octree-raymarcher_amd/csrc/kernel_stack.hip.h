@@ -117,6 +117,15 @@ __device__ __forceinline__ TraceArgs args_reloaded()
     __builtin_memcpy(&T, p, sizeof T);              // only the fields the caller uses survive (scalar loads)
     return T;
 }
+// camera f of the launch, read where it is needed with scalar loads at a uniform offset
+__device__ __forceinline__ FrameCam camera_reloaded(int f)
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    FrameCam c;
+    __builtin_memcpy(&c, (decltype(p))((const char __attribute__((address_space(4))) *)p + __builtin_offsetof(TraceArgs, cams) + (size_t)f * sizeof(FrameCam)), sizeof c);
+    return c;
+}
 
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
@@ -184,15 +193,16 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         unsigned long long dead = __ballot(mode == M_DONE);
         while (more && __popcll(dead) >= REFILL) {
             if (tile_next >= 64) {
-                int t32 = -1, tcol = 0, trow = 0;               // raster index of the tile, its column and row
+                int t32 = -1, tcol = 0, trow = 0, tframe = 0;   // raster index of the tile, its column and row, its frame
                 while (regions_left > 0) {
                     const int span = reg_q + (region < reg_rem ? 1 : 0);                    // columns (rows) of this region
                     const int first = region * reg_q + (region < reg_rem ? region : reg_rem);
-                    const int count = span * (by_cols ? tr_rows : tr_cols);
+                    const int count = span * (by_cols ? tr_rows : tr_cols);          // tiles of this region in one frame
                     unsigned long long tix = 0;
                     if (lane == 0) tix = atomicAdd(&A.work[WORK_CURSOR0 + region], 1ull);
-                    const int t = __builtin_amdgcn_readfirstlane((int)tix);
-                    if (t < count) {
+                    int t = __builtin_amdgcn_readfirstlane((int)tix);
+                    if (t < count * A.nframes) {                                    // frame after frame within the region
+                        if (A.nframes > 1) { tframe = t / count; t -= tframe * count; }
                         if (by_cols) { trow = t / span; tcol = first + (t - trow * span); }
                         else { trow = first + t / tr_cols; tcol = t % tr_cols; }
                         t32 = trow * tr_cols + tcol;
@@ -218,11 +228,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         const int lx = tcol * 8 + (lane & 7);
                         const int ly = trow * 8 + (lane >> 3);
                         ok = (lx < T.w) & (ly < T.h);
-                        k = ly * T.w + lx;
+                        k = (tframe * T.h + ly) * T.w + lx;
                         int px = 0, py = 0;
                         if (ok) local_to_pixel(T, lx, ly, px, py);
                         if (ok && (py >= T.imgh || px >= T.imgw)) { store_miss(A.out, k, 0); ok = false; }
-                        if (ok) camera_ray(T, px, py, o, d);
+                        if (ok) camera_ray(camera_reloaded(tframe), T.imgw, T.imgh, px, py, o, d);
                     } else {
                         ok = id < T.n;
                         k = id;

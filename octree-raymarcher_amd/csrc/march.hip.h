@@ -85,14 +85,14 @@ __device__ __forceinline__ int chunk_index(const TraceArgs &A, V3 p)
 }
 
 // The build's pinhole camera (include/svo.h svo_camera).
-__device__ __forceinline__ void camera_ray(const TraceArgs &A, int px, int py, V3 &o, V3 &d)
+__device__ __forceinline__ void camera_ray(const FrameCam &c, int imgw, int imgh, int px, int py, V3 &o, V3 &d)
 {
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const float u = ((fx / (float)A.imgw) * 2.0f - 1.0f) * A.tanx;
-    const float v = (1.0f - (fy / (float)A.imgh) * 2.0f) * A.tany;
-    const V3 dir = (ld3(A.fwd) + ld3(A.right) * u) + ld3(A.up) * v;
+    const float u = ((fx / (float)imgw) * 2.0f - 1.0f) * c.tanx;
+    const float v = (1.0f - (fy / (float)imgh) * 2.0f) * c.tany;
+    const V3 dir = (ld3(c.fwd) + ld3(c.right) * u) + ld3(c.up) * v;
     d = normalize3(dir);
-    o = ld3(A.eye);
+    o = ld3(c.eye);
 }
 
 // local raster position -> image pixel (rectangles and interleaved bands share this)

@@ -41,6 +41,11 @@ constexpr int TILE_REGIONS = 8;
 constexpr int WORK_CURSOR0 = 2;
 constexpr int WORK_SLOT_WORDS = 16;     // 128 B: slots do not share a cache line
 
+constexpr int MAX_FRAMES = 8;           // cameras one launch can march (svo_trace_frames)
+
+// one camera of the launch (include/svo.h svo_camera without the image size, which all frames share)
+struct FrameCam { float eye[3], fwd[3], right[3], up[3], tanx, tany; };
+
 struct TraceArgs {
     // world (src/Traverse.cpp:129-133: chunkmin/chunkmax of the whole grid)
     float    worldmin[3], worldmax[3];
@@ -52,8 +57,8 @@ struct TraceArgs {
     const uint64_t *mask;
     // rays
     int32_t  from_camera;       // 1: generate from cam; 0: origins/dirs
-    float    eye[3], fwd[3], right[3], up[3];
-    float    tanx, tany;
+    int32_t  nframes;           // camera mode: frames in this launch; frame f writes records [f*w*h, (f+1)*w*h)
+    FrameCam cams[MAX_FRAMES];
     float    inv_chunksize;     // exact when chunksize is a power of two (stack kernel only)
     int32_t  ccm[3];            // chunkcoordmin
     int32_t  cbase[3];          // positive_mod(chunkcoordmin, dims): index of the grid's first chunk per axis
@@ -71,7 +76,7 @@ struct TraceArgs {
     void     *out;              // svo_hit[n]
     uint32_t *counters;         // optional [n][4]
     unsigned long long *work;   // launch slot: [1] rays marched, [WORK_CURSOR0 + r] tile cursor of screen region r
-    int32_t  ntiles, tiles_per_row;
+    int32_t  ntiles, tiles_per_row;     // 8x8 tiles of ONE frame's raster (64-ray groups of the list in list mode)
 };
 
 } // namespace svo

@@ -38,8 +38,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     if "TCC_HIT_sum" in pmc:
         summary["l2_hit_rate"] = pmc["TCC_HIT_sum"]["mean_per_launch"] / (pmc["TCC_HIT_sum"]["mean_per_launch"] + pmc["TCC_MISS_sum"]["mean_per_launch"])
     wl = summary.get("prof_kt_bench_line", {}).get("config", {}).get("workload", "c3_1080p_depth12_4x1x4_shadow")
-    rec = {"hbm_bytes_per_launch": hbm, "source": f"profiles/{tag}_summary.json"}
-    if "SQ_INSTS_VALU" in pmc: rec["valu_insts_per_launch"] = pmc["SQ_INSTS_VALU"]["mean_per_launch"]
+    rec = {"hbm_bytes_per_frame": hbm, "source": f"profiles/{tag}_summary.json (PMC passes: one frame per launch)"}
+    if "SQ_INSTS_VALU" in pmc: rec["valu_insts_per_frame"] = pmc["SQ_INSTS_VALU"]["mean_per_launch"]
     json.dump({wl: rec}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if not k.endswith("bench_line")}, indent=1)[:3000])

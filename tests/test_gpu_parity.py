@@ -308,3 +308,55 @@ def test_tiles_per_wave_is_only_a_launch_shape(svo, worlds, tpw):
     W.trace(cam, svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tiles_per_wave=tpw), (0, 0, 203, 131), buf.ptr)
     svo.lib.svo_stream_synchronize(None)
     assert buf.to_numpy(svo.HIT_DTYPE, 203 * 131).tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("nframes", [1, 3, 8])
+def test_frames_in_one_launch_equal_separate_traces(svo, worlds, kernel, nframes):
+    """svo_trace_frames / svo_trace_rows_frames: F cameras behind one set of cursors == F separate launches."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    w, h = 171, 93
+    cams = [svo.make_camera((100.0 + 9.0 * f, 140.0 - 5.0 * f, -30.0 + 4.0 * f), (0.05 * f, -0.5, 0.8), (0.0, 1.0, 0.0), 50.0 + 3 * f, w, h)
+            for f in range(nframes)]
+    prm = svo.trace_params(shadow=True, kernel=_kid(svo, kernel), tiles_per_wave=2)
+    single = []
+    one = svo.DeviceBuffer(w * h * 32)
+    for c in cams:
+        W.trace(c, prm, (0, 0, w, h), one.ptr)
+        svo.lib.svo_stream_synchronize(None)
+        single.append(one.to_numpy(svo.HIT_DTYPE, w * h).copy())
+    allb = svo.DeviceBuffer(nframes * w * h * 32)
+    W.trace_frames(cams, prm, (0, 0, w, h), allb.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    got = allb.to_numpy(svo.HIT_DTYPE, nframes * w * h).reshape(nframes, w * h)
+    rays = W.last_ray_count()
+    for f in range(nframes):
+        assert got[f].tobytes() == single[f].tobytes(), f"frame {f} differs"
+    if kernel == "stack":
+        assert rays == sum(w * h + int((s["flags"] & 1).sum()) for s in single)
+    # interleaved bands of every frame (rank 1 of 3, 8-row bands; the last band hangs over the image)
+    nb = svo.partition.bands_per_rank(h, 3, 8)
+    bands = svo.DeviceBuffer(nframes * nb * 8 * w * 32)
+    W.trace_rows_frames(cams, prm, 1, 3, nb, 8, bands.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    gb = bands.to_numpy(svo.HIT_DTYPE, nframes * nb * 8 * w).reshape(nframes, nb, 8, w)
+    for f in range(nframes):
+        full = single[f].reshape(h, w)
+        for k in range(nb):
+            r0 = (1 + 3 * k) * 8
+            rows = min(8, max(0, h - r0))
+            assert gb[f, k, :rows].tobytes() == full[r0:r0 + rows].tobytes(), f"frame {f} band {k}"
+            assert not (gb[f, k, rows:]["flags"] & 1).any()
+
+
+def test_frames_argument_errors(svo, worlds):
+    W, O, lo, hi, _ = worlds["c1_depth8"]
+    buf = svo.DeviceBuffer(9 * 64 * 64 * 32)
+    cams = [svo.default_camera(1, 1, 128, 64, 64) for _ in range(9)]
+    with pytest.raises(svo.SvoError) as e:
+        W.trace_frames(cams, svo.trace_params(), (0, 0, 64, 64), buf.ptr)          # more than SVO_MAX_FRAMES
+    assert e.value.code == -1
+    mixed = [svo.default_camera(1, 1, 128, 64, 64), svo.default_camera(1, 1, 128, 32, 64)]
+    with pytest.raises(svo.SvoError) as e:
+        W.trace_frames(mixed, svo.trace_params(), (0, 0, 32, 32), buf.ptr)         # one image size per launch
+    assert e.value.code == -1
