@@ -218,8 +218,8 @@ def main():
             torch.cuda.synchronize()
 
     # ---- untimed: ray count of one frame (primary + shadow), all ranks
-    trace_group(0, 1)
-    rays_local = world.last_ray_count(streams[0].cuda_stream)
+    trace_group(0, G)                              # G identical views: every launch of this run has the same shape
+    rays_local = world.last_ray_count(streams[0].cuda_stream) // G
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
     rays_t = torch.tensor([rays_local], dtype=torch.int64, device=cdev)
     if multi:
@@ -239,9 +239,9 @@ def main():
         counters_sum = dict(node_words=csum[0], brick_cells=csum[1], chunk_descs=csum[2], tree_steps=csum[3])
         algo_bytes = 4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih
         # the fast kernel must have produced the same G-buffer as the literal one (cheap self-check, untimed)
-        trace_group(0, 1)
+        trace_group(0, G)
         torch.cuda.synchronize()
-        if not torch.equal(tmp, bufs[0][0]):
+        if not all(torch.equal(tmp, bufs[0][f]) for f in range(G)):
             raise SystemExit("bench.py: stack and literal kernels disagree on the benchmark frame")
         del tmp, cnt
 

@@ -16,6 +16,13 @@ int main(int argc, char **argv)
         svo_stream_synchronize(nullptr);
         size_t hits = 0, shadowed = 0;
         for (const svo_hit &h : gbuffer.download()) { hits += h.flags & SVO_HIT_FLAG; shadowed += (h.flags & SVO_SHADOWED) != 0; }
+        // two views (the frame's camera and one a step to the right) in one launch: svo_trace_frames
+        svo::Camera cam2({ 262.0f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, { 0.0f, 1.0f, 0.0f }, 60.0f, 640, 360);
+        svo::GBuffer pair;
+        world.draw_frames({ cam, cam2 }, pair, /*shadow=*/true);
+        svo_stream_synchronize(nullptr);
+        const std::vector<svo_hit> both = pair.download(), first = gbuffer.download();
+        if (std::memcmp(both.data(), first.data(), first.size() * sizeof(svo_hit)) != 0) { std::fprintf(stderr, "draw_frames: first view differs from draw\n"); return 3; }
         // Main.cpp:317 computeTarget.  (From exactly x = 256 this direction lies in a voxel-lattice plane: the
         // reference's 0 * inf = NaN makes that ray a miss, SURVEY.md App. C — so the cursor starts a little off it.)
         svo::vec3 sigma = { 0.0f, 0.0f, 0.0f };

@@ -127,6 +127,21 @@ public:
         check(svo_trace(world_, &cam, &p, 0, 0, cam.width, cam.height, out.device(), stream), "World::draw");
     }
 
+    // Several views in one launch (svo_trace_frames): `out` receives cams.size() rasters of cam size one after the
+    // other (a GBuffer of height cams.size() * cam.height holds them).  All cameras share one image size.
+    void draw_frames(const std::vector<Camera> &cams, GBuffer &out, bool shadow = false, const float light_dir[3] = nullptr, void *stream = nullptr)
+    {
+        if (cams.empty()) return;
+        const int w = cams[0].width, h = cams[0].height;
+        if (out.width != w || out.height != h * (int)cams.size()) out.resize(w, h * (int)cams.size());
+        svo_trace_params p;
+        std::memset(&p, 0, sizeof p);
+        p.shadow = shadow ? 1 : 0;
+        if (light_dir) std::memcpy(p.light_dir, light_dir, sizeof p.light_dir);
+        std::vector<svo_camera> plain(cams.begin(), cams.end());
+        check(svo_trace_frames(world_, plain.data(), (int)plain.size(), &p, 0, 0, w, h, out.device(), stream), "World::draw_frames");
+    }
+
     // World::modify(i, tree delta, twig delta): re-send an edited chunk (Ocdelta ranges, src/Octree.h:47-54).
     void modify(int i, const svo_chunk_desc &edited, uint64_t tree_left, uint64_t tree_right, uint64_t twig_left, uint64_t twig_right, bool realloc_)
     {
