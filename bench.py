@@ -55,8 +55,8 @@ FRAMES_PER_LAUNCH = {1: 4, 2: 8, 4: 8, 8: 8}       # consecutive frames marched 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_1080p_depth12_4x1x4_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "literal", "stack"])
     ap.add_argument("--streams", type=int, default=0,
