@@ -287,8 +287,9 @@ void svo_shade_defaults(svo_shade_params *p);
 int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
               const svo_hit *gbuffer_dev, float *rgba_dev, void *stream);
 
-/* Number of rays the last svo_trace* call on this world actually marched (primary + shadow);
- * synchronises `stream` internally — call it outside timed regions. */
+/* Number of rays the last launch on this world actually marched (primary + shadow, all frames of a
+ * svo_trace_frames launch; a multi-frame call served by a kernel other than SVO_KERNEL_STACK is one launch per
+ * frame and reports its last frame); synchronises `stream` internally — call it outside timed regions. */
 int svo_trace_last_ray_count(svo_world *, void *stream, uint64_t *rays);
 
 /* ---- small device helpers so that C/C++ callers need no HIP headers --------------------- */
