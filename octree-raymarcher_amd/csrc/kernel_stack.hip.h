@@ -6,7 +6,8 @@
 //
 //  * Persistent single-wave workgroups pull 8x8-pixel tiles (64 rays) from atomic cursors, one per screen region;
 //    a wave starts in the region of its XCD (HW_REG_XCC_ID), so each XCD's L2 serves one part of the world, and
-//    moves on to the other regions when its own is used up.
+//    moves on to the other regions when its own is used up.  One launch may carry several frames (cameras): a
+//    region's cursor then runs through its tiles frame after frame, and the waves drain once per launch.
 //    When >= REFILL lanes of the wave have retired (64-bit __ballot), the dead lanes are handed
 //    the next ray ids by prefix rank (mbcnt) — the wave re-compacts instead of idling on its
 //    slowest ray.  A primary hit turns its lane into the shadow ray in place.
@@ -26,7 +27,7 @@
 //  * The rare, expensive blocks (chunk step, G-buffer resolve of a primary hit) run only when a
 //    ballot shows enough lanes waiting for them (or nothing else is runnable).
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
-//    reference's own expressions instead of being held) so that 8 waves/SIMD fit.
+//    reference's own expressions instead of being held): 96 VGPRs, 5 waves per SIMD.
 //
 // All float arithmetic that decides t is evaluated exactly as in the reference; only loads and
 // integer bookkeeping differ.  Divisions by powers of two (chunk edge, node edge) are written as

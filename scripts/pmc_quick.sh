@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmcq -- python3 $R/bench.py --no-cpu-baseline --steps 4 --warmup 1 --streams 1 > $R/gpurun_out/pmcq.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmcq -- python3 $R/bench.py --no-cpu-baseline --steps 8 --warmup 4 --streams 1 > $R/gpurun_out/pmcq.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections,os
 R=os.environ['GRAFT_REPO_ROOT']
