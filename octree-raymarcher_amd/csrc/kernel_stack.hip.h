@@ -43,10 +43,10 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #define SVO_CREEP_ROUNDS 0       // >0: consecutive same-cell ("creeping") steps taken inside one iteration
 #endif
 #ifndef SVO_VOTE_WORLD
-#define SVO_VOTE_WORLD 12        // lanes waiting for a chunk step that make the wave run it
+#define SVO_VOTE_WORLD 8         // lanes waiting for a chunk step that make the wave run it
 #endif
 #ifndef SVO_VOTE_HIT
-#define SVO_VOTE_HIT 24          // primary hits waiting for their G-buffer record
+#define SVO_VOTE_HIT 16          // primary hits waiting for their G-buffer record
 #endif
 #ifndef SVO_VOTE_BUSY
 #define SVO_VOTE_BUSY 24         // fewer marching lanes than this: serve the waiting ones regardless
