@@ -5,14 +5,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 svo = importlib.import_module("octree-raymarcher_amd")
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # frames per launch
 W = svo.World.generate(4, 1, 4, 128, depth); W.upload(0)
 cam = svo.default_camera(4, 4, 128, 1920, 1080)
 nblk = 256 * 32
-out = svo.DeviceBuffer(1920 * 1080 * 32)
+out = svo.DeviceBuffer(F * 1920 * 1080 * 32)
 for rep in range(3):
     cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 8), np.uint32))
     prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, counters_dev=cnt.ptr)
-    W.trace(cam, prm, (0, 0, 1920, 1080), out.ptr)
+    W.trace_frames([cam] * F, prm, (0, 0, 1920, 1080), out.ptr)
     svo.lib.svo_stream_synchronize(None)
     c8 = cnt.to_numpy(np.uint32, nblk * 8).reshape(nblk, 8); c = c8[:, :4]; e = c8[:, 4:]
 e = e[c[:, 2] > 0]; c = c[c[:, 2] > 0]
