@@ -135,8 +135,6 @@ def main():
     # launches' bulk fills; with N ranks a rank's share of a frame shrinks N-fold, so more frames ride in one launch
     # (both tables measured with --emulate-share)
     S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    stream = torch.cuda.current_stream().cuda_stream
     # F consecutive frames form one group: ONE launch marches them (svo_trace_frames: the persistent waves drain once
     # per launch, not once per frame) and, at N > 1, ONE gather ships them.  Group j runs on stream j % S.
     if args.frames_per_launch > 0:
@@ -146,6 +144,10 @@ def main():
     else:
         G = FRAMES_PER_LAUNCH.get(max(world_size, args.emulate_share, 1), 4)
     G = max(1, min(G, svo.MAX_FRAMES))
+    if args.frames_per_launch <= 0 and args.frames_per_gather <= 0:
+        G = max(1, min(G, args.steps // S))     # a short run: fewer frames per launch rather than idle streams
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    stream = torch.cuda.current_stream().cuda_stream
 
     nb = svo.partition.bands_per_rank(ih, world_size, BAND)     # bands per rank (last ones may be padding)
     rec = 32
