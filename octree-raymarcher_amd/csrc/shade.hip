@@ -20,13 +20,14 @@ struct ShadeArgs {
     int32_t imgw, imgh, x0, y0, w, h;
     const uint4 *gbuffer;
     float4 *rgba;
+    // per-launch constants worked out once on the host with the same float expressions the per-pixel code used:
+    float gdiffuse[8][3], gspecular[8][3];      // pow(material.diffuse / .specular, gamma), :183-184
+    float dir_l[3], spot_axis[3];               // normalize(-directional.direction), normalize(-spot.direction)
 };
 
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ float length3(V3 v) { return sqrtf(dot3(v, v)); }
-__device__ __forceinline__ V3 neg(V3 v) { return mk(-v.x, -v.y, -v.z); }
 __device__ __forceinline__ float maxf0(float x) { return (x < 0.0f) ? 0.0f : x; }          // max(x, 0.0)
-__device__ __forceinline__ V3 pow3(V3 v, float e) { return mk(powf(v.x, e), powf(v.y, e), powf(v.z, e)); }
 __device__ __forceinline__ float attenuation(float kc, float kl, float kq, float d) { return 1.0f / (kc + kl * d + kq * d * d); }   // :75-78
 
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
     const V3 p = eye + beta * (t - P.eps);
     const V3 n = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
     const svo_material &M = P.materials[material < 8 ? material : 0];
-    const V3 diffuse = pow3(ld3(M.diffuse), P.gamma), specular = pow3(ld3(M.specular), P.gamma);     // :183-184
+    const V3 diffuse = ld3(A.gdiffuse[material < 8 ? material : 0]), specular = ld3(A.gspecular[material < 8 ? material : 0]);     // :183-184
     const float lit = (flags & SVO_SHADOWED) ? 0.0f : 1.0f;                                          // (1.0 - shadow)
     const V3 vdir = normalize3(eye - p);
     V3 color = mk(0.0f, 0.0f, 0.0f);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
         color = color + ((amb + dif) + spe) * att;
     }
     {   // computeDirectionalLight_BlinnPhong, :99-114
-        const V3 l = normalize3(neg(ld3(P.directional.direction)));
+        const V3 l = ld3(A.dir_l);
         const V3 hv = normalize3(l + vdir);
         const float d = maxf0(dot3(n, l));
         const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
         const float d = maxf0(dot3(n, l));
         const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
         const float att = attenuation(P.spot.constant, P.spot.linear, P.spot.quadratic, length3(p - ld3(P.spot.position)));
-        const float theta = dot3(l, normalize3(neg(ld3(P.spot.direction))));
+        const float theta = dot3(l, ld3(A.spot_axis));
         const float delta = P.spot.cos_phi - P.spot.cos_gamma;
         float intensity = (theta - P.spot.cos_gamma) / delta;
         intensity = (intensity < 0.0f) ? 0.0f : intensity;                      // clamp = min(max(x, 0), 1)
@@ -202,6 +203,18 @@ int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, 
     std::memcpy(A.eye, cam->eye, 12); std::memcpy(A.fwd, cam->forward, 12); std::memcpy(A.right, cam->right, 12); std::memcpy(A.up, cam->up, 12);
     A.tanx = cam->tan_half_x; A.tany = cam->tan_half_y; A.imgw = cam->width; A.imgh = cam->height;
     A.x0 = x0; A.y0 = y0; A.w = w; A.h = h;
+    for (int m = 0; m < 8; ++m)
+        for (int c = 0; c < 3; ++c) {
+            A.gdiffuse[m][c] = std::pow(A.P.materials[m].diffuse[c], A.P.gamma);
+            A.gspecular[m][c] = std::pow(A.P.materials[m].specular[c], A.P.gamma);
+        }
+    auto unit_neg = [](const float v[3], float out[3]) {          // glm::normalize(-v) = -v * (1 / sqrt(dot))
+        const float x = -v[0], y = -v[1], z = -v[2];
+        const float inv = 1.0f / std::sqrt(x * x + y * y + z * z);
+        out[0] = x * inv; out[1] = y * inv; out[2] = z * inv;
+    };
+    unit_neg(A.P.directional.direction, A.dir_l);
+    unit_neg(A.P.spot.direction, A.spot_axis);
     A.gbuffer = reinterpret_cast<const uint4 *>(gbuffer_dev);
     A.rgba = reinterpret_cast<float4 *>(rgba_dev);
     const int64_t n = (int64_t)w * h;
