@@ -239,7 +239,8 @@ int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *p
                    int band0, int band_stride, int nbands, int band_height,
                    svo_hit *out_dev, void *stream);
 
-/* Several frames in ONE launch: nframes (1..SVO_MAX_FRAMES) cameras of one image size, the same rectangle / bands of
+/* Several World::draw calls (src/World.cpp:205-266; the reference issues two marches per displayed frame, the light's
+ * and the eye's, src/Main.cpp:190-222) in ONE launch: nframes (1..SVO_MAX_FRAMES) cameras of one image size, the same rectangle / bands of
  * each; frame f's records follow frame f-1's in out_dev (nframes consecutive rasters).  Results are those of nframes
  * separate svo_trace / svo_trace_rows calls.  What it buys: the stack kernel's persistent waves run through all the
  * frames' tiles behind one set of cursors, so they drain once per launch instead of once per frame (stereo pairs,
