@@ -17,7 +17,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def svo():
-    """The product binding; importing it fails loudly when libsvo_amd.so is missing."""
+    """The product binding.  `make` first (a no-op when libsvo_amd.so is up to date; hipcc cross-compiles without a GPU),
+    so that a fresh checkout tests the real HIP library; importing fails loudly when it is still missing - there is no
+    CPU fallback to test instead."""
+    import subprocess
+    if not os.environ.get("SVO_AMD_LIB"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "octree-raymarcher_amd")], check=True, stdout=subprocess.DEVNULL)
     return importlib.import_module("octree-raymarcher_amd")
 
 
