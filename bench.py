@@ -48,8 +48,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BAND = 8                       # rows per band == tile height of the stack kernel
-STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 8}       # launches in flight per rank when a frame is split N ways (measured)
-FRAMES_PER_LAUNCH = {1: 4, 2: 8, 4: 8, 8: 8}       # consecutive frames marched by one launch (and shipped by one gather)
+STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways (measured)
+FRAMES_PER_LAUNCH = {1: 4, 2: 8, 4: 16, 8: 16}      # consecutive frames marched by one launch (and shipped by one gather)
 
 
 def main():

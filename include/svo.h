@@ -245,7 +245,7 @@ int svo_trace_rows(svo_world *, const svo_camera *cam, const svo_trace_params *p
  * separate svo_trace / svo_trace_rows calls.  What it buys: the stack kernel's persistent waves run through all the
  * frames' tiles behind one set of cursors, so they drain once per launch instead of once per frame (stereo pairs,
  * cube-map faces, shadow cascades, several viewports, or simply the next frames of a pipelined renderer). */
-#define SVO_MAX_FRAMES 8
+#define SVO_MAX_FRAMES 16
 int svo_trace_frames(svo_world *, const svo_camera *cams, int nframes, const svo_trace_params *params,
                      int x0, int y0, int w, int h, svo_hit *out_dev, void *stream);
 int svo_trace_rows_frames(svo_world *, const svo_camera *cams, int nframes, const svo_trace_params *params,

@@ -117,7 +117,7 @@ class WorldInfo(C.Structure):
 
 
 # every symbol include/svo.h declares (tests check that the library exports exactly these)
-MAX_FRAMES = 8                      # SVO_MAX_FRAMES
+MAX_FRAMES = 16                     # SVO_MAX_FRAMES
 
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",

@@ -359,7 +359,7 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
 
 static int fill_cameras(const svo_camera *cams, int nframes, TraceArgs &A)
 {
-    if (!cams || nframes < 1 || nframes > MAX_FRAMES) { set_error("svo_trace: between 1 and 8 cameras per launch"); return SVO_ERR_INVALID_ARG; }
+    if (!cams || nframes < 1 || nframes > MAX_FRAMES) { set_error("svo_trace: between 1 and 16 cameras per launch"); return SVO_ERR_INVALID_ARG; }
     for (int f = 0; f < nframes; ++f) {
         const svo_camera &c = cams[f];
         if (c.width <= 0 || c.height <= 0) { set_error("svo_trace: bad camera"); return SVO_ERR_INVALID_ARG; }

@@ -41,7 +41,7 @@ constexpr int TILE_REGIONS = 8;
 constexpr int WORK_CURSOR0 = 2;
 constexpr int WORK_SLOT_WORDS = 16;     // 128 B: slots do not share a cache line
 
-constexpr int MAX_FRAMES = 8;           // cameras one launch can march (svo_trace_frames)
+constexpr int MAX_FRAMES = 16;          // cameras one launch can march (svo_trace_frames)
 
 // one camera of the launch (include/svo.h svo_camera without the image size, which all frames share)
 struct FrameCam { float eye[3], fwd[3], right[3], up[3], tanx, tany; };

@@ -311,7 +311,7 @@ def test_tiles_per_wave_is_only_a_launch_shape(svo, worlds, tpw):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("nframes", [1, 3, 8])
+@pytest.mark.parametrize("nframes", [1, 3, 16])
 def test_frames_in_one_launch_equal_separate_traces(svo, worlds, kernel, nframes):
     """svo_trace_frames / svo_trace_rows_frames: F cameras behind one set of cursors == F separate launches."""
     W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
@@ -351,8 +351,8 @@ def test_frames_in_one_launch_equal_separate_traces(svo, worlds, kernel, nframes
 
 def test_frames_argument_errors(svo, worlds):
     W, O, lo, hi, _ = worlds["c1_depth8"]
-    buf = svo.DeviceBuffer(9 * 64 * 64 * 32)
-    cams = [svo.default_camera(1, 1, 128, 64, 64) for _ in range(9)]
+    buf = svo.DeviceBuffer(17 * 64 * 64 * 32)
+    cams = [svo.default_camera(1, 1, 128, 64, 64) for _ in range(svo.MAX_FRAMES + 1)]
     with pytest.raises(svo.SvoError) as e:
         W.trace_frames(cams, svo.trace_params(), (0, 0, 64, 64), buf.ptr)          # more than SVO_MAX_FRAMES
     assert e.value.code == -1
