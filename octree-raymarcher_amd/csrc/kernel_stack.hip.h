@@ -39,9 +39,6 @@ namespace svo {
 
 enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 
-#ifndef SVO_CREEP_ROUNDS
-#define SVO_CREEP_ROUNDS 0       // >0: consecutive same-cell ("creeping") steps taken inside one iteration
-#endif
 #ifndef SVO_VOTE_WORLD
 #define SVO_VOTE_WORLD 8         // lanes waiting for a chunk step that make the wave run it
 #endif
