@@ -14,6 +14,9 @@
  *   svo_world_update     <- World::modify + RootAllocator::subst   src/World.cpp:268-274, src/Allocator.cpp:37-55
  *   svo_trace            <- World::draw (+ draw_shadowmap)         src/World.cpp:162-266
  *                           fragment main                          shaders/World.Fragment.glsl:162-203
+ *   svo_trace_frames     <- several World::draw calls in one launch (the frame's light and eye passes,
+ *                           src/Main.cpp:190-222; stereo / split-screen views; a pipelined renderer's next frames)
+ *   svo_trace_rows(_frames) <- the same over the interleaved row bands of one rank (multi-GPU partition)
  *   svo_trace_rays       <- chunkmarch over a ray list             src/Traverse.cpp:127-171
  *   svo_world_destroy    <- World::deinit                          src/World.cpp:129-151
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
