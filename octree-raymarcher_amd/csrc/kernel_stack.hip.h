@@ -48,6 +48,14 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #ifndef SVO_VOTE_BUSY
 #define SVO_VOTE_BUSY 24         // fewer marching lanes than this: serve the waiting ones regardless
 #endif
+// Creeping rays (see the creep block in the kernel): a lane whose last SVO_CREEP_SERIOUS steps all advanced by ~EPS makes
+// the wave run the creep block; SVO_CREEP_LANES creeping lanes do so at once.
+#ifndef SVO_CREEP_SERIOUS
+#define SVO_CREEP_SERIOUS 6
+#endif
+#ifndef SVO_CREEP_LANES
+#define SVO_CREEP_LANES 8
+#endif
 
 // 1/x for x an exact power of two (normal range): exponent negation, no division sequence.
 __device__ __forceinline__ float recip_pow2(float x) { return __uint_as_float(0x7F000000u - __float_as_uint(x)); }
@@ -135,12 +143,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
+    unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0;   // block runs, lane-steps taken in it (this lane), rounds
 #endif
 
     const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
     const V3 sdir = ld3(A.sdir);
     const V3 sg = recip(sdir);                      // 1/sdir: the same quotient for every shadow ray
     const float eps = A.eps;
+    const bool eps_pow2 = (__float_as_uint(eps) & 0x807FFFFFu) == 0u && __float_as_uint(eps) >= 0x00800000u && __float_as_uint(eps) < 0x7F800000u;
     const float csize = A.chunksize;
 
     // ---- wave state (uniform) ------------------------------------------------------------
@@ -179,12 +189,15 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     V3 clo = mk(0, 0, 0);
     const uint32_t *tree = A.tree;
     uint32_t twig_off = 0;
-    int levels = 0, ci = 0;
+    int levels = 0, ci = -1;
     // descent cache: cell coordinates of the last tree step and the level of the node it ended at
     int pux = 0, puy = 0, puz = 0, valid = 0;
     // brick
     unsigned long long bmask = 0;
     uint32_t hitc = SVO_CELL_NONE;  // M_HIT: which brick cell (or none: LEAF)
+    // creeping rays: |creepn| = consecutive advances of this ray by less than 2 EPS (kept across level changes: a ray pinned
+    // on a chunk face creeps at every level); > 0 only while the cell located last is known to be empty (creep block armed)
+    int creepn = 0;
 
     for (;;) {
         // ==== refill retired lanes =============================================================
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     g = mk(tile_ray[6][slot], tile_ray[7][slot], tile_ray[8][slot]);
                     tw = tile_ray[9][slot];
                     is_shadow = false;
-                    cw = 0; guard = 0;
+                    cw = 0; guard = 0; creepn = 0;
                     mode = M_WORLD;
                 }
             }
@@ -287,7 +300,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const int n_busy = __popcll(__ballot(mode == M_TREE || mode == M_TWIG));
         const int n_world = __popcll(__ballot(mode == M_WORLD));
         const int n_hit = __popcll(__ballot(mode == M_HIT));
-        const bool run_world = n_world > 0 && (n_world >= SVO_VOTE_WORLD || n_busy < SVO_VOTE_BUSY);
+        const bool run_world = n_world > 0 && (n_world >= SVO_VOTE_WORLD || n_busy < SVO_VOTE_BUSY ||
+                                               __ballot(mode == M_WORLD && creepn <= -SVO_CREEP_SERIOUS) != 0ull);
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
         if (mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD) {     // runaway ray: give up, flag it
@@ -308,7 +322,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const V3 p = alpha + beta * tw;
                 miss = !inside(p, wlo, whi);
                 if (!miss) {
-                    ci = chunk_index_pow2(A, p);
+                    const int ci_new = chunk_index_pow2(A, p);
+                    // The descent cache (stk column, pux/puy/puz, valid) is keyed by chunk and cell, not by ray: a ray that
+                    // enters the chunk this lane marched last - a shadow ray leaving its primary hit, the next pixel of the
+                    // tile, a ray pinned on a chunk face - restarts below the deepest common level instead of at the root.
+                    if (ci_new != ci) valid = 0;
+                    ci = ci_new;
                     const DevChunk ch = A.chunks[ci];
                     clo = ld3(ch.bmin);
                     miss = !inside(p, clo, clo + csize);
@@ -320,7 +339,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         Blo = clo; Bsize = csize;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
                         inv_res = recip_pow2(res); cap = A.cap_tree;
-                        valid = 0;
                         mode = M_TREE;
                     }
                 }
@@ -337,6 +355,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
+            const int crept = creepn < 0 ? -creepn : creepn;
+            creepn = -crept;                                        // disarmed unless this step advances (see the creep block)
             bool leave = cnt >= cap;
             cnt += leave ? 0 : 1;
             const V3 p = O + beta * t;
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
                 if (!leave) {
                     t += e;
+                    creepn = e < 2.0f * eps ? crept + 1 : 0;        // pinned on a lattice plane: see the creep block
                 } else if (twig) {                                  // back to the tree level that entered the brick
                     t = tt_saved + e;
                     cnt = it_saved;
@@ -441,6 +462,93 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
         }
 
+        // ---- creep block.  A ray that sits exactly on a lattice plane (p.a == lo.a of its cell) and moves towards the
+        //      negative side of axis a by less than one ulp per step gets cubeEscapeDistance == -0 and advances by EPS
+        //      alone (src/Traverse.cpp:25-32 has no guard against it; the GLSL twin's BIGEPS, shaders/Chunkmarch.glsl:107-114,
+        //      is not CPU semantics) - for up to thousands of steps in the same empty cell, each one a full step of the
+        //      general path.  The wave takes such steps here, in a tight loop without descent or loads, one reference step
+        //      per round: while the next position q = O + beta*t
+        //        (1) still lies in the cell located last, lo <= q < hi (tree: that is the cell the descent would find;
+        //            brick: the truncated cell index is checked as well, src/Traverse.cpp:58), which is known to be empty,
+        //        (2) is pinned, q.a == lo.a with beta.a < 0 on some axis a, and
+        //        (3) 1/beta is finite on all axes (no 0 * inf = NaN in the escape evaluation),
+        //      the reference's escape is max((lo.a-q.a)*g.a, (hi.a-q.a)*g.a) = max(-0, negative) = -0 on axis a and
+        //      >= +0 or -0 on the others, its glm::min chain yields -0, and the step is t += (-0 + EPS) = EPS, counters
+        //      included.  Anything else hands the lane back to the general step, which recomputes from the same state.
+        {
+            const bool cr = creepn > 0 && (mode == M_TREE || mode == M_TWIG);
+            const unsigned long long crm = __ballot(cr);
+            if (crm != 0ull && eps_pow2 && (__ballot(cr && creepn >= SVO_CREEP_SERIOUS) != 0ull || __popcll(crm) >= SVO_CREEP_LANES)) {
+                const bool twig = mode == M_TWIG;
+                const float finite_max = __uint_as_float(0x7F7FFFFFu);
+                bool go = cr && (fabsf(g.x) <= finite_max) && (fabsf(g.y) <= finite_max) && (fabsf(g.z) <= finite_max);
+                const V3 q0 = O + beta * t;                         // where the next reference step starts
+                V3 lo;
+                float fvx = 0.0f, fvy = 0.0f, fvz = 0.0f;            // brick: the cell's lattice coordinates as floats
+                float size;
+                if (!twig) {                                        // the EMPTY node located by the last tree step
+                    const int low = (1 << (levels - valid)) - 1;
+                    lo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
+                    size = res * (float)(low + 1);
+                } else {                                            // the brick cell q0 lies in, if it is an empty one
+                    go &= inside(q0, Blo, Blo + Bsize);
+                    const int vx = (int)((q0.x - Blo.x) * inv_res), vy = (int)((q0.y - Blo.y) * inv_res), vz = (int)((q0.z - Blo.z) * inv_res);
+                    go &= (vx <= 3) & (vy <= 3) & (vz <= 3);
+                    go = go && !((bmask >> (vz * 16 + vy * 4 + vx)) & 1ull);
+                    fvx = (float)vx; fvy = (float)vy; fvz = (float)vz;
+                    lo = mk(Blo.x + fvx * res, Blo.y + fvy * res, Blo.z + fvz * res);
+                    size = res;
+                }
+                const V3 hi = lo + size;
+                // the next step itself must be a pinned one: (1) and (2) at q0
+                go &= (q0.x >= lo.x) & (q0.y >= lo.y) & (q0.z >= lo.z) & (q0.x < hi.x) & (q0.y < hi.y) & (q0.z < hi.z);
+                go &= ((beta.x < 0.0f) & (q0.x == lo.x)) | ((beta.y < 0.0f) & (q0.y == lo.y)) | ((beta.z < 0.0f) & (q0.z == lo.z));
+#ifdef SVO_STACK_TIMING
+                ++n_creep_runs;
+#endif
+                // How many such steps follow each other?  q's components are monotone (rounded) functions of t and the
+                // ray came from inside the cell, so (1) holds for a prefix of the steps, and an axis pinned at q0 stays
+                // pinned for as long as (1) holds: "step k is a pinned step" is true for k < K and false from K on.
+                // While t_0 and EPS (a power of two) are multiples of ulp(t_k), the reference's t_k = t_{k-1} + EPS
+                // equals t_0 + k*EPS without rounding.  K is found by bit descent - 14 probes instead of K rounds -
+                // and the K steps are taken at once.
+                int K = 0;
+                const int kmax = min(cap - cnt, (int)(STEP_GUARD - guard));
+                const uint32_t t0b = __float_as_uint(t);
+                const int e_eps = (int)(__float_as_uint(eps) >> 23);
+                bool up = true;                                     // first double the probe (short creeps end here), then descend
+                for (int b = 1; b > 0;) {
+#ifdef SVO_STACK_TIMING
+                    ++n_creep_rounds;
+#endif
+                    const int cand = up ? b : K + b;
+                    const float tk = t + (float)(cand - 1) * eps;   // position before the cand-th step
+                    const float tn = t + (float)cand * eps;         // parameter after it: must be exact
+                    const int e_n = (int)(__float_as_uint(tn) >> 23), shift = e_n - (int)(t0b >> 23);
+                    bool ok = go && cand <= kmax && e_n - 23 <= e_eps && tn < __uint_as_float(0x7F800000u);
+                    ok = ok && (t0b == 0u || (t0b >= 0x00800000u && shift < 24 && (((t0b & 0x007FFFFFu) | 0x00800000u) & ((1u << shift) - 1u)) == 0u));
+                    const V3 q = O + beta * tk;
+                    ok &= (q.x >= lo.x) & (q.y >= lo.y) & (q.z >= lo.z) & (q.x < hi.x) & (q.y < hi.y) & (q.z < hi.z);
+                    if (twig) {                                     // the reference's own cell index must agree (truncation of a rounded difference)
+                        const float fx = (q.x - Blo.x) * inv_res, fy = (q.y - Blo.y) * inv_res, fz = (q.z - Blo.z) * inv_res;
+                        ok &= (fx >= fvx) & (fx < fvx + 1.0f) & (fy >= fvy) & (fy < fvy + 1.0f) & (fz >= fvz) & (fz < fvz + 1.0f);
+                    }
+                    K = ok ? cand : K;
+                    if (!up) b >>= 1;
+                    else if (__ballot(ok) == 0ull) { up = false; b >>= 2; }      // every lane: K <= b/2, bits below that are open
+                    else if (b >= (1 << 13)) { up = false; b >>= 1; }
+                    else b <<= 1;
+                }
+                if (K > 0) {
+                    t += (float)K * eps;                            // == K times t + (escape + EPS) with escape == -0
+                    cnt += K; guard += (uint32_t)K; creepn += K;
+#ifdef SVO_STACK_TIMING
+                    n_creep_steps += K;
+#endif
+                }
+            }
+        }
+
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && is_shadow) {
@@ -475,7 +583,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             if (A.shadow) {                             // the lane becomes its own shadow ray
                 alpha = point; beta = sdir; g = sg;
                 is_shadow = true;
-                tw = 0.0f; cw = 0; guard = 0;
+                tw = 0.0f; cw = 0; guard = 0; creepn = 0;
                 bool hit = true;
                 if (!inside(alpha, wlo, whi)) tw = enter(alpha, beta, wlo, whi, hit) + eps;
                 mode = hit ? M_WORLD : M_DONE;          // a shadow ray that misses the world box stays "lit"
@@ -490,9 +598,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_STACK_TIMING
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
-        reinterpret_cast<uint4 *>(A.counters)[2 * blockIdx.x] = c;
+        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
-        reinterpret_cast<uint4 *>(A.counters)[2 * blockIdx.x + 1] = e;
+        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 1] = e;
+        uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = 0;
+        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 2] = f;
     }
 #endif
 }

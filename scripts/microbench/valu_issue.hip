@@ -1,0 +1,105 @@
+// valu_issue.hip — how many cycles does one wave64 VALU instruction hold a gfx950 SIMD for?
+//
+// W waves per SIMD (W = 1..8) each run a stream of independent VALU instructions (8 accumulators, so that the
+// dependent-issue latency never gates the stream).  Per wave: s_memtime before and after; cycles per instruction per
+// SIMD = elapsed / (instructions per wave * W) because the W waves of a SIMD share its issue port for that interval.
+// The same figure follows from the launch's wall time (HIP events) and the shader clock.  Mixes measured: v_fma_f32,
+// v_add_u32, v_bfe_u32, v_cmp+v_cndmask (the march step's compare/select pairs), v_mul_f32 + v_cvt.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue > valu_issue.json
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum { OP_FMA = 0, OP_ADDU = 1, OP_BFE = 2, OP_CMPSEL = 3, OP_MULCVT = 4, N_OPS = 5 };
+static const char *op_name[N_OPS] = { "v_fma_f32", "v_add_u32", "v_bfe_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_mul_f32+v_cvt_i32_f32" };
+static const int op_insts[N_OPS] = { 1, 1, 1, 2, 2 };     // VALU instructions per "op" below
+
+constexpr int UNROLL = 8;       // independent accumulators
+constexpr int INNER = 16;       // ops per accumulator per loop trip (loop overhead: 2 SALU per 128+ VALU)
+
+template <int OP>
+__global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned long long *cycles, float *sink)
+{
+    float a[UNROLL];
+    unsigned u[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed + (float)(threadIdx.x + i); u[i] = threadIdx.x * 7u + i; }
+    const float m = 1.0000001f, c = 1e-7f;
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int k = 0; k < INNER; ++k) {
+#pragma unroll
+            for (int i = 0; i < UNROLL; ++i) {
+                if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (OP == OP_ADDU) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % UNROLL]));
+                if (OP == OP_BFE) asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(u[i]));
+                if (OP == OP_CMPSEL) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(m), "v"(c) : "vcc");
+                if (OP == OP_MULCVT) asm volatile("v_mul_f32 %0, %0, %2\n\tv_cvt_i32_f32 %1, %0" : "+v"(a[i]), "=v"(u[i]) : "v"(m));
+            }
+        }
+    }
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.0f; unsigned q = 0;
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) { s += a[i]; q += u[i]; }
+    if (s == 12345.678f && q == 42u) sink[0] = s;             // keep the streams alive
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+template <int OP>
+static void run(int waves_per_simd, int ncu, double clock_ghz, bool last)
+{
+    const int trips = 2000;
+    const int blocks = ncu * 4 * waves_per_simd;               // 64-thread blocks: the dispatcher spreads them over the SIMDs
+    unsigned long long *d_cyc; float *d_sink;
+    CHECK(hipMalloc(&d_cyc, blocks * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&d_sink, 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, 10, 1.0f, d_cyc, d_sink);    // warm
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, trips, 1.0f, d_cyc, d_sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> cyc(blocks);
+    CHECK(hipMemcpy(cyc.data(), d_cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::sort(cyc.begin(), cyc.end());
+    const double insts = (double)trips * INNER * UNROLL * op_insts[OP];      // VALU instructions per wave
+    const double med = (double)cyc[blocks / 2], p10 = (double)cyc[blocks / 10], p90 = (double)cyc[blocks * 9 / 10];
+    // wall-clock view: every SIMD issues insts * W instructions in ms
+    const double wall_cyc_per_inst = (ms * 1e-3 * clock_ghz * 1e9) / (insts * waves_per_simd);
+    printf("    {\"op\": \"%s\", \"waves_per_simd\": %d, \"valu_insts_per_wave\": %.0f, \"wave_cycles_median\": %.0f, "
+           "\"wave_cycles_p10\": %.0f, \"wave_cycles_p90\": %.0f, \"cycles_per_inst_per_simd\": %.3f, "
+           "\"launch_ms\": %.4f, \"cycles_per_inst_per_simd_from_wall_at_%.1fGHz\": %.3f}%s\n",
+           op_name[OP], waves_per_simd, insts, med, p10, p90, med / (insts * waves_per_simd), ms, clock_ghz, wall_cyc_per_inst, last ? "" : ",");
+    CHECK(hipFree(d_cyc)); CHECK(hipFree(d_sink));
+}
+
+int main()
+{
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    const double ghz = prop.clockRate * 1e-6;
+    printf("{\n  \"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_ghz\": %.3f,\n", prop.name, prop.gcnArchName, ncu, ghz);
+    printf("  \"note\": \"cycles_per_inst_per_simd = median wave s_memtime cycles / (VALU insts per wave * waves per SIMD); 8 independent accumulators per wave\",\n");
+    printf("  \"runs\": [\n");
+    const int ws[] = { 1, 2, 4, 5, 8 };
+    for (int w : ws) {
+        run<OP_FMA>(w, ncu, ghz, false);
+        run<OP_ADDU>(w, ncu, ghz, false);
+        run<OP_BFE>(w, ncu, ghz, false);
+        run<OP_CMPSEL>(w, ncu, ghz, false);
+        run<OP_MULCVT>(w, ncu, ghz, w == 8);
+    }
+    printf("  ]\n}\n");
+    return 0;
+}

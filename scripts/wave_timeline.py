@@ -8,15 +8,17 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # frames per launch
 W = svo.World.generate(4, 1, 4, 128, depth); W.upload(0)
 cam = svo.default_camera(4, 4, 128, 1920, 1080)
+if os.environ.get("SVO_BENCH_EYE_DX"):
+    cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
 nblk = 256 * 32
 out = svo.DeviceBuffer(F * 1920 * 1080 * 32)
 for rep in range(3):
-    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 8), np.uint32))
+    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 12), np.uint32))
     prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, counters_dev=cnt.ptr)
     W.trace_frames([cam] * F, prm, (0, 0, 1920, 1080), out.ptr)
     svo.lib.svo_stream_synchronize(None)
-    c8 = cnt.to_numpy(np.uint32, nblk * 8).reshape(nblk, 8); c = c8[:, :4]; e = c8[:, 4:]
-e = e[c[:, 2] > 0]; c = c[c[:, 2] > 0]
+    c8 = cnt.to_numpy(np.uint32, nblk * 12).reshape(nblk, 12); c = c8[:, :4]; e = c8[:, 4:8]; f = c8[:, 8:]
+e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; c = c[c[:, 2] > 0]
 t0 = c[:, 0].min()
 st = (c[:, 0] - t0).astype(np.int64) * 0.01      # us
 en = (c[:, 1] - t0).astype(np.int64) * 0.01
@@ -27,7 +29,7 @@ it = c[:, 2].astype(np.int64)
 print("iters  p50 %d p99 %d max %d   us/iter p50 %.2f" % (np.percentile(it, 50), np.percentile(it, 99), it.max(), np.median((en - st) / it)))
 late = np.argsort(en)[-8:]
 for i in late:
-    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i]))
+    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d lane0-steps %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1]))
 for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
     print("t=%5d us running waves: %d" % (t, ((st <= t) & (en > t)).sum()))
 
@@ -39,3 +41,4 @@ print("block runs per iteration: world %.3f hit %.3f refill-rounds %.3f tilegen 
     (ex & 0xFFFF).sum() / its, (ex >> 16).sum() / its, (ey & 0xFFF).sum() / its, ((ey >> 12) & 0xFF).sum() / its, (ey >> 20).sum() / its))
 print("avg lanes per iteration: tree %.1f twig %.1f world %.1f" % (e[:, 2].astype(np.int64).sum() / its, (e[:, 3] & 0xFFFFF).astype(np.int64).sum() / its, (e[:, 3] >> 20).astype(np.int64).sum() / its))
 print("cycles per wave-iteration overall: %.0f" % (tot_wave_cycles / its))
+print("creep block: runs per iteration %.4f, rounds per run %.1f" % (f[:, 0].astype(np.int64).sum() / its, f[:, 2].astype(np.int64).sum() / max(1, f[:, 0].astype(np.int64).sum())))
