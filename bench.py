@@ -43,7 +43,7 @@ WORKLOADS = {
     "c2_1080p_depth10_1chunk": (1, 1, 1, 10, 1920, 1080, False),           # BASELINE configs[1]
     "c3small_1080p_depth10_4x1x4_shadow": (4, 1, 4, 10, 1920, 1080, True),  # quick rehearsal of c3
     "c4_2160p_depth12_4x1x4_shadow": (4, 1, 4, 12, 3840, 2160, True),      # BASELINE configs[3]
-    "c5_1080p_depth16_sparse_shadow": (1, 1, 1, 16, 1920, 1080, True),     # BASELINE configs[4]: full depth in a 1-unit band
+    "c5_1080p_depth16_sparse_shadow": (1, 1, 1, 16, 1920, 1080, True),     # BASELINE configs[4]: full depth in a 4-unit band
     "c3_grazing_1080p_depth12_4x1x4_shadow": (4, 1, 4, 12, 1920, 1080, True),   # SURVEY §8d second camera: inside the world, looking along it
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -112,8 +112,7 @@ def main():
     # ---- world: generated on the host (deterministic -> identical on every rank), resident in HBM
     t0 = time.time()
     if args.workload.startswith("c5_"):
-        world = svo.World.generate(gw, gh, gd, 128, depth, pyramid_resolution=4096, water=False, coarse_depth=10,
-                                   refine_box=((63.5, -1e9, -1e9), (64.5, 1e9, 1e9)))
+        world = svo.World.generate(gw, gh, gd, 128, depth, **svo.c5_scene()["generate"])
     else:
         world = svo.World.generate(gw, gh, gd, 128, depth)
     t_gen = time.time() - t0
@@ -125,7 +124,7 @@ def main():
     if "grazing" in args.workload:
         cam = svo.make_camera((250.3, 90.0, 5.0), (0.06, -0.04, 1.0), (0.0, 1.0, 0.0), 60.0, iw, ih)       # long, shallow marches
     if args.workload.startswith("c5_"):
-        cam = svo.make_camera((64.2, 150.0, -40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, iw, ih)   # over the refined band
+        cam = svo.c5_scene()["camera"](iw, ih)                  # hovering over the refined band
     if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
         cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
     # a 1/N share of the frame is small: with several frames in flight, waves that keep refilling (>= 4 tiles each) beat

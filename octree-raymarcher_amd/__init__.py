@@ -240,6 +240,16 @@ def default_camera(world_w: int, world_d: int, chunksize: int, width: int, heigh
     return make_camera((cx, 150.0, -40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, width, height)
 
 
+def c5_scene() -> dict:
+    """BASELINE.json configs[4] as tests and bench.py build it: one depth-16 chunk refined to full depth only inside
+    the band 62 <= x <= 66 (depth-10 bricks elsewhere; 13.4 M nodes, 2.5 M bricks), seen by a camera hovering 2 units
+    over the band's terrain, so that a third of the primary hits are depth-16 voxels (14 branch levels on the path)."""
+    return {
+        "generate": dict(pyramid_resolution=4096, water=False, coarse_depth=10, refine_box=((62.0, -1e9, -1e9), (66.0, 1e9, 1e9))),
+        "camera": lambda w, h: make_camera((64.3, 12.7, 96.5), (0.0, -0.8, 0.6), (0.0, 1.0, 0.0), 60.0, w, h),
+    }
+
+
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
                  caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0) -> TraceParams:
     p = TraceParams()

@@ -64,11 +64,32 @@ def test_c3_1080p_depth12_4x1x4_shadow(svo, oracle, c3):
     assert 0.3 < (want["flags"] & 1).mean() < 0.9 and ((want["flags"] & 4) != 0).sum() > 10000
 
 
-def test_c4_2160p_band_partition_of_8(svo, c3):
+def test_c3_off_lattice_eye(svo, oracle, c3):
+    """The benchmark camera moved 0.31 off the chunk seam x = 256: the pixel column with the smallest |dir.x| now creeps
+    along lattice planes for up to ~5 300 steps per pixel (on the seam those rays have dir.x == 0 and NaN-miss).  Both
+    kernels against the oracle over the whole 1080p frame."""
+    O = oracle.OracleWorld.from_chunks([c3.chunk(i, copy=False) for i in range(16)], 4, 1, 4, 128)
+    cam = svo.default_camera(4, 4, 128, 1920, 1080)
+    cam.eye[0] += 0.31
+    want, wc = O.trace_image(cam, params=oracle.make_params(shadow=True), counters=True, threads=THREADS)
+    steps = wc[..., 1].astype(np.int64) + wc[..., 2] + wc[..., 3]
+    assert steps.max() > 3000                   # the creeping column is in the picture
+    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        got = c3.draw(cam, shadow=True, kernel=k)
+        assert_gbuffer_equal(got, want, f"c3-off-lattice/{k}")
+    check_properties(svo, got, True)
+
+
+def test_c4_2160p_band_partition_of_8(svo, oracle, c3):
     """configs[3]: the 3840x2160 image as 8 ranks would trace it (8-row bands round-robin) equals the whole frame;
-    every rank's bands are traced here on the one GPU and de-interleaved with the bench's helper."""
+    every rank's bands are traced here on the one GPU and de-interleaved with the bench's helper.  The whole frame is
+    also compared with the oracle, record for record."""
     cam = svo.default_camera(4, 4, 128, 3840, 2160)
     full = c3.draw(cam, shadow=True)
+    O = oracle.OracleWorld.from_chunks([c3.chunk(i, copy=False) for i in range(16)], 4, 1, 4, 128)
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=THREADS)
+    assert_gbuffer_equal(full, want, "c4/whole frame vs oracle")
+    del want
     part = svo.partition
     n = 8
     nb = part.bands_per_rank(2160, n)
@@ -84,20 +105,42 @@ def test_c4_2160p_band_partition_of_8(svo, c3):
     check_properties(svo, full, True)
 
 
+def node_levels(tree):
+    """Level of every node of a BFS-ordered chunk tree (src/Octree.cpp:98-104,165-173): level l+1 holds the 8 children
+    of each BRANCH of level l, in order.  Returns the index of the first node of each level."""
+    starts, pos, count = [0], 0, 1
+    while count > 0 and pos < tree.size:
+        branches = int(((tree[pos:pos + count] >> 30) == 2).sum())
+        pos += count
+        count = 8 * branches
+        starts.append(pos)
+    return np.array(starts)
+
+
 def test_c5_depth16_sparse(svo, oracle):
-    """configs[4]: depth-16 sparse SVO (full depth only inside a 1-unit band, bricks at depth 10 elsewhere): 14 branch
-    levels exercise the deepest LDS-stack instantiation; whole 1080p image against the oracle."""
-    W = svo.World.generate(1, 1, 1, 128, 16, pyramid_resolution=4096, water=False, coarse_depth=10,
-                           refine_box=((63.5, -1e9, -1e9), (64.5, 1e9, 1e9)))
+    """configs[4]: depth-16 sparse SVO (full depth only inside the band 62 <= x <= 66, bricks at depth 10 elsewhere):
+    14 branch levels exercise the deepest LDS-stack instantiation.  The camera hovers over the band, so a large part of
+    the picture is depth-16 voxels (bricks under nodes of level 14, edge 128/65536); whole 1080p image against the oracle."""
+    scene = svo.c5_scene()
+    W = svo.World.generate(1, 1, 1, 128, 16, **scene["generate"])
     assert W.info.max_chunk_depth == 16 and W.info.exact_geometry == 1
-    O = oracle.OracleWorld.from_chunks([W.chunk(0, copy=False)], 1, 1, 1, 128)
+    chunk = W.chunk(0, copy=False)
+    O = oracle.OracleWorld.from_chunks([chunk], 1, 1, 1, 128)
     W.upload(0)
-    cam = svo.make_camera((64.2, 150.0, -40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, 1920, 1080)
+    cam = scene["camera"](1920, 1080)
     want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=THREADS)
     got = W.draw(cam, shadow=True, kernel=svo.KERNEL_STACK)
     assert_gbuffer_equal(got, want, "c5/stack")
     check_properties(svo, got, True)
-    # the refined band is actually hit: some hit voxels are depth-16 voxels (nodes at level 14 -> brick cells of 128/65536)
+    lit = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL)
+    assert_gbuffer_equal(lit, want, "c5/literal")
+    # the deep part of the tree is what the picture shows: >= 25 % of the primary hits end at a node of level 14 (a brick
+    # of depth-16 voxels or a LEAF of that level: 14 BRANCH levels above it), the rest at coarse depth-10 bricks
+    starts = node_levels(chunk["tree"])
+    assert len(starts) - 2 == 14                                    # deepest level that holds nodes
     hit = (want["flags"] & 1) != 0
-    assert hit.mean() > 0.1
+    level = np.searchsorted(starts, want["node"], side="right") - 1
+    deep = hit & (level == 14)
+    assert hit.mean() > 0.5
+    assert deep.sum() >= 0.25 * hit.sum(), f"only {deep.sum() / hit.sum():.3f} of the hits sit at level 14"
     W.destroy()

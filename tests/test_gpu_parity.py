@@ -7,7 +7,7 @@ which is what the kernels are built to deliver).
 import numpy as np
 import pytest
 
-from helpers import assert_gbuffer_equal, chunks_of, random_rays
+from helpers import FUZZ_CASES, adversarial_rays, assert_gbuffer_equal, chunks_of, creeping_rays, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -360,3 +360,48 @@ def test_frames_argument_errors(svo, worlds):
     with pytest.raises(svo.SvoError) as e:
         W.trace_frames(mixed, svo.trace_params(), (0, 0, 32, 32), buf.ptr)         # one image size per launch
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["grid_2x1x2_d6", "grid_neg_2x2x2_d5", "depth10"])
+@pytest.mark.parametrize("eps,caps,chunk_faces", [
+    (0.0, (0, 0, 0), False),                  # EPS 1/8192, caps 1000/1000/1000: creeps of thousands of steps, cut by the caps
+    (1.0 / 4096.0, (40, 300, 25), True),      # another power of two; small caps end the creeps in the middle of a run
+    (0.0, (20, 0, 60), True),                 # pinned on chunk faces: chunkmarch, treemarch and twigmarch creep together
+    (1.0e-4, (0, 0, 0), False),               # not a power of two: the stack kernel's closed form does not apply, the general step does
+])
+def test_creeping_rays(svo, oracle, worlds, name, kernel, eps, caps, chunk_faces):
+    """Rays pinned on lattice planes (src/Traverse.cpp:25-32: escape == -0, t += EPS per step).  The stack kernel takes
+    such stretches in closed form (kernel_stack.hip.h, creep block); every record must still equal the oracle's, which
+    walks them step by step - including the step caps running out inside a stretch (src/Traverse.cpp:54,79,142)."""
+    W, O, lo, hi, s = worlds[name]
+    rng = np.random.default_rng(77)
+    o, d = creeping_rays(rng, 6000, lo, hi, 128.0 / (1 << s["depth"]), chunk_faces)
+    prm = oracle.make_params(shadow=True, eps=eps, caps=caps)
+    want, wc = O.trace_rays(o, d, params=prm, counters=True, threads=8)
+    steps = wc[:, 1].astype(np.int64) + wc[:, 2] + wc[:, 3]
+    assert steps.max() < (1 << 22)            # below the kernels' runaway guard (SVO_ERR_FLAG)
+    got = W.chunkmarch(o, d, shadow=True, kernel=_kid(svo, kernel), eps=eps, caps=caps)
+    assert_gbuffer_equal(got, want, f"creep/{name}/{kernel}")
+    # the list really contains long creeps: rays with far more steps than any ordinary ray of these worlds takes
+    assert (steps > 400).sum() >= 5 and (want["flags"] & 1).sum() > 300
+
+
+def test_fuzz_one_million_adversarial_rays(svo, oracle):
+    """A 1 M-ray cut of scripts/fuzz_parity.py: four worlds (negative chunk coordinates, depth 6-11), two lights, both
+    kernels, every record against the oracle."""
+    threads = 16
+    for i, c in enumerate(FUZZ_CASES):
+        W = svo.World.generate(c["w"], c["h"], c["d"], 128, c["depth"], chunkcoordmin=c["ccm"])
+        n = c["w"] * c["h"] * c["d"]
+        O = oracle.OracleWorld.from_chunks([W.chunk(j, copy=False) for j in range(n)], c["w"], c["h"], c["d"], 128, c["ccm"])
+        W.upload(0)
+        lo = np.array(c["ccm"], float) * 128
+        hi = lo + np.array([c["w"], c["h"], c["d"]]) * 128
+        o, d = adversarial_rays(np.random.default_rng(1000 + i), 125000, lo, hi)
+        for light in ((1.0, -1.0, 0.0), (0.2, -0.9, 0.4)):
+            want = O.trace_rays(o, d, params=oracle.make_params(shadow=True, light_dir=light), threads=threads)
+            for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+                got = W.chunkmarch(o, d, shadow=True, kernel=k, light_dir=light)
+                assert_gbuffer_equal(got, want, f"fuzz {c} kernel {k} light {light}")
+        W.destroy()
