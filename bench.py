@@ -8,10 +8,19 @@ written to HBM.  World pools are resident in HBM before the timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Frames are pipelined: F consecutive frames (F cameras - here F views of the benchmark camera) are
-marched by ONE launch (svo_trace_frames: the kernel's persistent waves run through all F frames'
-tiles and drain once per launch instead of once per frame), and S such launches are in flight on S
-HIP streams.  K steps = K frames = ceil(K/F) launches (the last one may be short).
+Without a launcher (`WORLD_SIZE` unset) and N > 1 the script starts its own N rank processes (multiprocessing
+"spawn", before anything touches HIP) and exits non-zero if any of them fails.
+
+The frames follow a deterministic CAMERA PATH (`--camera-path orbit`, default): frame i is seen by camera
+i mod P of P = 32 distinct views - the SURVEY.md §8d camera (eye on the chunk seam x = 256) first, then an orbit
+whose eyes sit off the voxel lattice (x offset 0.31 + ..., the positions where rays creep along lattice planes), and
+the "grazing" camera inside the world last.  `value` = all rays of the K timed frames / wall time.  The per-camera
+spread (each camera timed alone, serialized) and the identical-view figure of round 1 (`--camera-path fixed`: every
+frame the same camera) are reported beside it as diagnostics.
+
+Frames are pipelined: F consecutive frames (F cameras of the path) are marched by ONE launch (svo_trace_frames: the
+kernel's persistent waves run through all F frames' tiles and drain once per launch instead of once per frame), and
+S such launches are in flight on S HIP streams.  K steps = K frames = ceil(K/F) launches (the last one may be short).
 
 N > 1: the image is partitioned into 8-row bands dealt round-robin to the ranks (rank r traces
 bands r, r+N, ...; every rank holds the whole world), and each launch ends with ONE RCCL gather of
@@ -20,16 +29,18 @@ its F frames' per-rank G-buffer bands (packed losslessly to 8 B/pixel) to rank 0
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (k_trace_stack) against the
 8 TB/s HBM peak using the ALGORITHMIC bytes of the reference algorithm: per ray
-4*node_words + 2*brick_cells + 32*chunk_descriptors (restart-from-root counts, measured for this
-exact frame by the literal kernel's counters) + 32 B G-buffer record per pixel.  `cpu_baseline`
-is the CPU oracle (oracle/, a port of src/Traverse.cpp) timed on this host on the same frame.
+4*node_words + 2*brick_cells + 32*chunk_descriptors (restart-from-root counts, measured for these
+exact frames by the literal kernel's counters) + 32 B G-buffer record per pixel.  `cpu_baseline`
+is the CPU oracle (oracle/, a port of src/Traverse.cpp) timed on this host on one frame of the path.
 """
 from __future__ import annotations
 
 import argparse
 import importlib
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -46,19 +57,51 @@ WORKLOADS = {
     "c5_1080p_depth16_sparse_shadow": (1, 1, 1, 16, 1920, 1080, True),     # BASELINE configs[4]: full depth in a 4-unit band
     "c3_grazing_1080p_depth12_4x1x4_shadow": (4, 1, 4, 12, 1920, 1080, True),   # SURVEY §8d second camera: inside the world, looking along it
 }
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_STREAM_GBS = 6300.0        # ... and what a streaming copy achieves (6.29 TB/s measured)
 BAND = 8                       # rows per band == tile height of the stack kernel
-STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways (measured)
+STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways (one-GPU emulation, unmeasured on N GPUs)
 FRAMES_PER_LAUNCH = {1: 4, 2: 8, 4: 16, 8: 16}      # consecutive frames marched by one launch (and shipped by one gather)
+PATH_CAMERAS = 32
 
 
-def main():
+def camera_path(svo, workload, gw, gd, iw, ih, count=PATH_CAMERAS):
+    """The deterministic camera path of the run: camera 0 is the workload's base view, cameras 1.. an
+    orbit around it with eyes off the voxel lattice and a swinging view direction; C3-family workloads end with the
+    grazing camera.  Plain float64 arithmetic, rounded to float32 by make_camera: the same path on every host."""
+    if workload.startswith("c5_"):
+        base_eye, base_fwd = (64.3, 12.7, 96.5), (0.0, -0.8, 0.6)          # svo.c5_scene(): hovering over the refined band
+        span, rise, reach = 1.3, 0.6, 2.0
+    elif "grazing" in workload:
+        base_eye, base_fwd = (250.3, 90.0, 5.0), (0.06, -0.04, 1.0)
+        span, rise, reach = 30.0, 4.0, 15.0
+    else:
+        base_eye, base_fwd = (gw * 128 * 0.5, 150.0, -40.0), (0.0, -0.5, 0.866)
+        span, rise, reach = 0.29 * gw * 128 * 0.5, 5.0, 21.0
+    cams = [svo.make_camera(base_eye, base_fwd, (0.0, 1.0, 0.0), 60.0, iw, ih)]
+    for k in range(1, count):
+        th = 2.0 * math.pi * k / count
+        eye = (base_eye[0] + 0.31 + span * math.sin(th), base_eye[1] + 0.07 + rise * math.sin(2.0 * th),
+               base_eye[2] + 0.13 + reach * (1.0 - math.cos(th)))
+        yaw = 0.22 * math.sin(th)
+        fx, fy, fz = base_fwd
+        fwd = (fx * math.cos(yaw) + fz * math.sin(yaw), fy + 0.08 * (math.cos(2.0 * th) - 1.0), -fx * math.sin(yaw) + fz * math.cos(yaw))
+        cams.append(svo.make_camera(eye, fwd, (0.0, 1.0, 0.0), 60.0, iw, ih))
+    if workload.startswith(("c3_1080p", "c3small", "c4_")):
+        cams[-1] = svo.make_camera((250.3, 90.0, 5.0), (0.06, -0.04, 1.0), (0.0, 1.0, 0.0), 60.0, iw, ih)   # grazing: long, shallow marches
+    return cams
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_1080p_depth12_4x1x4_shadow", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "literal", "stack"])
+    ap.add_argument("--camera-path", default="orbit", choices=["orbit", "fixed"],
+                    help="orbit = 32 distinct views incl. off-lattice eyes and the grazing camera (the metric); fixed = every frame "
+                         "is the SURVEY camera (round-1 figure: identical rays in flight share every cache line)")
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight: frame i is issued on HIP stream i %% S into G-buffer i %% S, so the long-ray "
                          "tail of one frame overlaps the bulk of the next (1 = strictly serialized frames)")
@@ -73,8 +116,112 @@ def main():
     ap.add_argument("--frames-per-gather", type=int, default=0, help="older name of --frames-per-launch at N > 1")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic (N > 1): trace only, skip the per-frame gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the per-camera spread and the identical-view leg")
     ap.add_argument("--cpu-crop", type=int, default=0, help="time the CPU oracle on a centred NxN crop instead of the full frame")
-    args = ap.parse_args()
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="no GPU, no tracing: run the N-rank control flow (self-spawn, rendezvous, ranks_seen, band partition, "
+                         "gather to rank 0, de-interleave) on synthetic band buffers over gloo; used by the CPU test suite")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="--spawn-selftest: this rank exits with an error (exit-code propagation test)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# self-spawn: `python bench.py --gpus N` without a launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_entry(rank, world_size, port, argv):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world_size), "LOCAL_WORLD_SIZE": str(world_size),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SVO_BENCH_SPAWNED": "1"})
+    run(parse_args(argv))
+
+
+def spawn_ranks(args, argv):
+    """Start args.gpus fresh rank processes (spawn: nothing of this process's state - in particular no HIP context - is
+    inherited; never exec) and wait; any failing rank fails the run."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, port, argv), name=f"bench-rank{r}") for r in range(args.gpus)]
+    for p in procs:
+        p.start()
+    failed = None
+    while failed is None and any(p.is_alive() for p in procs):
+        for p in procs:
+            p.join(timeout=0.2)
+            if p.exitcode not in (None, 0):
+                failed = p
+                break
+    if failed is None:
+        for p in procs:
+            p.join()
+        bad = [p for p in procs if p.exitcode != 0]
+        failed = bad[0] if bad else None
+    if failed is not None:
+        for p in procs:                         # the others would wait in a collective forever: stop exactly the processes started here
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+        raise SystemExit(f"bench.py: rank process {failed.name} exited with code {failed.exitcode}")
+
+
+def spawn_selftest(args, rank, world_size):
+    """The N-rank control flow without a GPU: rendezvous, ranks_seen, band partition, gather, de-interleave."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "octree-raymarcher_amd"))
+    part = importlib.import_module("partition")                 # pure host logic; the package itself needs the HIP library
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    if rank == args.selftest_fail_rank:
+        raise SystemExit(3)
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(seen)
+    ih, iw, prec = 116, 40, 8                                   # ragged: 14.5 bands
+    nb = part.bands_per_rank(ih, world_size, BAND)
+    mine = torch.zeros((nb, BAND, iw, prec), dtype=torch.uint8)
+    for k in range(nb):
+        for j, y in enumerate(part.band_rows(rank, world_size, k, BAND)):
+            mine[k, j] = (y * 7 + rank) % 251                  # a pattern the de-interleaved frame can be checked against
+    gathered = [torch.empty_like(mine) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)
+    if rank == 0:
+        frame = part.deinterleave(gathered, ih, BAND)
+        ok = frame.shape[0] == ih
+        for y in range(ih):
+            ok = ok and bool((frame[y] == (y * 7 + (y // BAND) % world_size) % 251).all())
+        if not ok:
+            raise SystemExit("bench.py --spawn-selftest: de-interleaved frame is wrong")
+        print(json.dumps({"spawn_selftest": True, "ranks_seen": int(seen.item()), "n_gpus": world_size,
+                          "launcher": "self-spawned" if os.environ.get("SVO_BENCH_SPAWNED") else "external",
+                          "frame_rows": ih, "bands_per_rank": nb}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, list(sys.argv[1:] if argv is None else argv))
+    return run(args)
+
+
+def run(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
+    if args.spawn_selftest:
+        return spawn_selftest(args, rank, world_size)
 
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, at most 4 frames'
     # kernels are really in flight and 1/N-frame shares cannot hide their long-ray tails.  Must be set before HIP starts.
@@ -83,14 +230,9 @@ def main():
     import torch                                   # before the library: one HIP runtime per process
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     # rehearsal aid: run the N > 1 control flow (bands, pack, collective, self-check) with a single rank, e.g. to
     # exercise the RCCL calls on a one-GPU box
     multi = world_size > 1 or bool(os.environ.get("SVO_BENCH_FORCE_DIST"))
-    if world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the SVO march has no CPU fallback")
     if args.backend == "gloo":
@@ -109,30 +251,32 @@ def main():
     gw, gh, gd, depth, iw, ih, shadow = WORKLOADS[args.workload]
     kernel = {"auto": svo.KERNEL_AUTO, "literal": svo.KERNEL_LITERAL, "stack": svo.KERNEL_STACK}[args.kernel]
 
-    # ---- world: generated on the host (deterministic -> identical on every rank), resident in HBM
+    # ---- world: generated by every rank for itself (deterministic -> identical everywhere), resident in HBM.
+    # The ranks of one node share its host cores: each takes its share of the threads.
+    local_ranks = int(os.environ.get("LOCAL_WORLD_SIZE", str(world_size)))
+    gen_threads = max(1, (os.cpu_count() or 1) // max(1, local_ranks))
     t0 = time.time()
     if args.workload.startswith("c5_"):
-        world = svo.World.generate(gw, gh, gd, 128, depth, **svo.c5_scene()["generate"])
+        world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, **svo.c5_scene()["generate"])
     else:
-        world = svo.World.generate(gw, gh, gd, 128, depth)
+        world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads)
     t_gen = time.time() - t0
     t0 = time.time()
     world.upload(local_rank)
     t_up = time.time() - t0
     info = world.info
-    cam = svo.default_camera(gw, gd, 128, iw, ih)
-    if "grazing" in args.workload:
-        cam = svo.make_camera((250.3, 90.0, 5.0), (0.06, -0.04, 1.0), (0.0, 1.0, 0.0), 60.0, iw, ih)       # long, shallow marches
-    if args.workload.startswith("c5_"):
-        cam = svo.c5_scene()["camera"](iw, ih)                  # hovering over the refined band
-    if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the eye off the lattice plane
-        cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
+    path = camera_path(svo, args.workload, gw, gd, iw, ih)
+    if os.environ.get("SVO_BENCH_EYE_DX"):                      # experiments only: move the base eye off the lattice plane
+        path[0].eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
+    if args.camera_path == "fixed":
+        path = [path[0]]
+    P = len(path)
     # a 1/N share of the frame is small: with several frames in flight, waves that keep refilling (>= 4 tiles each) beat
     # one wave per tile (+6 % at 1/8 share); no effect on a full 1080p frame, which has more tiles than resident waves
     prm = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)
     # launches in flight: a launch's critical path is its longest ray, so its tail leaves SIMDs idle that the next
     # launches' bulk fills; with N ranks a rank's share of a frame shrinks N-fold, so more frames ride in one launch
-    # (both tables measured with --emulate-share)
+    # (both tables measured with --emulate-share on ONE GPU; unmeasured on real multi-GPU hardware)
     S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
     # F consecutive frames form one group: ONE launch marches them (svo_trace_frames: the persistent waves drain once
     # per launch, not once per frame) and, at N > 1, ONE gather ships them.  Group j runs on stream j % S.
@@ -145,6 +289,8 @@ def main():
     G = max(1, min(G, svo.MAX_FRAMES))
     if args.frames_per_launch <= 0 and args.frames_per_gather <= 0:
         G = max(1, min(G, args.steps // S))     # a short run: fewer frames per launch rather than idle streams
+    if args.kernel == "literal":
+        G = 1                                   # the literal kernel is one launch per frame (svo_trace_last_ray_count reports one frame)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -164,11 +310,14 @@ def main():
         pbufs = [torch.empty((G, nb, BAND, iw, prec), dtype=torch.uint8, device=dev) for _ in range(S)]
         gdev = dev if args.backend == "nccl" else torch.device("cpu")
         gathered = [[torch.empty(pbufs[0].shape, dtype=torch.uint8, device=gdev) for _ in range(world_size)] for _ in range(S)] if rank == 0 else [None] * S
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
 
-    def trace_group(slot, k):
-        """One launch: k <= G frames (here: k views of the same camera) into bufs[slot][:k] on stream `slot`."""
+    def cams_of(first, k, fixed=None):
+        return [fixed] * k if fixed is not None else [path[(first + f) % P] for f in range(k)]
+
+    def trace_group(slot, cams):
+        """One launch: len(cams) <= G frames into bufs[slot][:k] on stream `slot`."""
         st = streams[slot].cuda_stream
-        cams = [cam] * k
         if multi:
             world.trace_rows_frames(cams, prm, rank, world_size, nb, BAND, bufs[slot].data_ptr(), st)
         elif share:
@@ -176,7 +325,7 @@ def main():
         else:
             world.trace_frames(cams, prm, (0, 0, iw, ih), bufs[slot].data_ptr(), st)
 
-    def frame(i, works, events=None, last=False):
+    def frame(i, works, events=None, last=False, gather=True, fixed=None):
         """Frame i joins its group; the group's last frame issues the launch (and, at N > 1, pack + gather to rank 0)."""
         slot, sub = (i // G) % S, i % G
         if not (sub == G - 1 or last):
@@ -190,12 +339,12 @@ def main():
             if events is not None:
                 events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), k))
                 events[-1][0].record(st)
-            trace_group(slot, k)
+            trace_group(slot, cams_of(i - sub, k, fixed))
             if events is not None:
                 events[-1][1].record(st)
             if multi:
                 svo.gbuffer_pack(bufs[slot].data_ptr(), pbufs[slot].data_ptr(), k * nb * BAND * iw, st.cuda_stream)
-                if not args.no_gather:
+                if gather:
                     src = pbufs[slot][:k]
                     dst = [g[:k] for g in gathered[slot]] if rank == 0 else None
                     if args.backend == "nccl":
@@ -218,32 +367,64 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- untimed: ray count of one frame (primary + shadow), all ranks
-    trace_group(0, G)                              # G identical views: every launch of this run has the same shape
-    rays_local = world.last_ray_count(streams[0].cuda_stream) // G
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")
-    rays_t = torch.tensor([rays_local], dtype=torch.int64, device=cdev)
+    def timed_region(steps, gather=True, fixed=None, events=None):
+        """Exactly `steps` frames, barrier + synchronize on both sides; returns max-over-ranks seconds."""
+        works = [None] * S
+        sync_all()
+        t_start = time.perf_counter()
+        for i in range(steps):
+            frame(i, works, events, last=(i == steps - 1), gather=gather, fixed=fixed)
+        drain(works)
+        sync_all()
+        dt = time.perf_counter() - t_start
+        if multi:
+            et = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            dt = float(et.item())
+        return dt
+
+    # ---- untimed: rays of every camera of the path (primary + shadow; this rank's share, then summed over the ranks)
+    rays_local = []
+    for c in path:
+        trace_group(0, [c])
+        rays_local.append(world.last_ray_count(streams[0].cuda_stream))
+    rays_t = torch.tensor(rays_local, dtype=torch.int64, device=cdev)
+    seen_t = torch.ones(1, dtype=torch.int64, device=cdev)
     if multi:
         dist.all_reduce(rays_t)
-    rays_frame = int(rays_t.item())
+        dist.all_reduce(seen_t)                     # how many ranks the collective backend really connects
+    rays_cam = [int(v) for v in rays_t.tolist()]
+    ranks_seen = int(seen_t.item())
+    devices = [torch.cuda.current_device()]
+    if multi:
+        dl = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world_size)]
+        dist.all_gather(dl, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=cdev))
+        devices = [int(d.item()) for d in dl]
 
-    # ---- untimed, rank 0 at N=1: algorithmic bytes of this frame from the reference work counters
-    algo_bytes = None
+    def rays_of(steps, fixed=False):
+        return steps * rays_cam[0] if fixed else sum(rays_cam[i % P] for i in range(steps))
+
+    # ---- untimed, N=1: algorithmic bytes of every camera's frame from the reference work counters, and the
+    # stack-vs-literal self-check of every distinct frame
+    algo_cam = None
     counters_sum = None
     if not multi and not args.emulate_share:
+        algo_cam = []
+        counters_sum = dict(node_words=0, brick_cells=0, chunk_descs=0, tree_steps=0)
         cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
         tmp = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
         cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
-        world.trace(cam, cprm, (0, 0, iw, ih), tmp.data_ptr(), stream)
-        torch.cuda.synchronize()
-        csum = cnt.to(torch.int64).sum(dim=0).tolist()
-        counters_sum = dict(node_words=csum[0], brick_cells=csum[1], chunk_descs=csum[2], tree_steps=csum[3])
-        algo_bytes = 4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih
-        # the fast kernel must have produced the same G-buffer as the literal one (cheap self-check, untimed)
-        trace_group(0, G)
-        torch.cuda.synchronize()
-        if not all(torch.equal(tmp, bufs[0][f]) for f in range(G)):
-            raise SystemExit("bench.py: stack and literal kernels disagree on the benchmark frame")
+        for ci, c in enumerate(path):
+            world.trace(c, cprm, (0, 0, iw, ih), tmp.data_ptr(), stream)
+            torch.cuda.synchronize()
+            csum = cnt.to(torch.int64).sum(dim=0).tolist()
+            for key, v in zip(list(counters_sum), csum):
+                counters_sum[key] += v
+            algo_cam.append(4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih)
+            trace_group(0, [c])                     # the fast kernel must produce the literal kernel's G-buffer
+            torch.cuda.synchronize()
+            if not torch.equal(tmp, bufs[0][0]):
+                raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
         del tmp, cnt
 
     # ---- warmup
@@ -251,60 +432,84 @@ def main():
     for i in range(args.warmup):
         frame(i, works, last=(i == args.warmup - 1))
     drain(works)
-    works = [None] * S
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     ev = []                                     # (start, end, frames) per launch
-    sync_all()
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        frame(i, works, ev, last=(i == args.steps - 1))
-    drain(works)
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    if multi:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+    elapsed = timed_region(args.steps, gather=not args.no_gather, events=ev)
     assert sum(k for _, _, k in ev) == args.steps
     kernel_ms = [a.elapsed_time(b) for a, b, _ in ev]
     kernel_ms_overlapped = sum(kernel_ms) / len(kernel_ms)      # per launch while S launches share the GPU
+    lastf = args.steps - 1
+    last_slot, last_sub = (lastf // G) % S, lastf % G
+    last_out = bufs[last_slot][:last_sub + 1].clone()            # the last timed launch's G-buffers (parity sample below)
+    if rank == 0 and multi and not args.no_gather:
+        last_gathered = [g[last_sub].clone() for g in gathered[last_slot]]
+
+    # ---- diagnostics, untimed by the contract
+    diag = {}
+    if multi and not args.no_gather:
+        dt = timed_region(args.steps, gather=False)             # the same frames without the exchange step
+        diag["trace_only_mrays"] = round(rays_of(args.steps) / dt / 1e6, 3)
+    if not multi and not share and not args.no_diagnostics:
+        if P > 1:
+            dt = timed_region(args.steps, fixed=path[0])        # round-1 figure: every frame in flight is the same view
+            diag["identical_view_mrays"] = round(rays_of(args.steps, fixed=True) / dt / 1e6, 3)
+        # each camera alone: one serialized launch of G frames of that camera (second of two)
+        per_cam = []
+        st0 = streams[0]
+        for ci, c in enumerate(path):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(st0):
+                world.trace_frames([c] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                a.record(st0)
+                world.trace_frames([c] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                b.record(st0)
+            st0.synchronize()
+            per_cam.append(rays_cam[ci] * G / (a.elapsed_time(b) * 1e-3) / 1e6)
+        diag["per_camera_serialized_mrays"] = {
+            "min": round(min(per_cam), 1), "median": round(statistics.median(per_cam), 1), "max": round(max(per_cam), 1),
+            "camera0_on_lattice": round(per_cam[0], 1), "slowest_camera": int(per_cam.index(min(per_cam))),
+            "all": [round(v) for v in per_cam],
+            "how": f"each of the {P} path cameras alone: one launch of {G} frames of that camera, back to back on one stream"}
 
     # ---- roofline leg (N=1): the kernel's own launch duration.  With launches in flight the per-launch time above
-    # measures co-scheduling (S launches share the SIMDs), so the dominant kernel - one launch of G frames, as in the
-    # timed region - is also timed back-to-back on ONE stream with HIP events on that stream; rocprofv3 --kernel-trace
-    # of `bench.py --streams 1` must agree.
+    # measures co-scheduling (S launches share the SIMDs), so the dominant kernel - one launch of G consecutive path
+    # frames, as in the timed region - is also timed back-to-back on ONE stream with HIP events on that stream;
+    # rocprofv3 --kernel-trace of `bench.py --streams 1` must agree.
     kernel_ms_avg = kernel_ms_overlapped
+    roof_bytes = None
     if not multi and not args.emulate_share:
-        reps = max(5, min(args.steps // G, 20))
+        reps = max(5, min(args.steps // G, 2 * P // G if P > 1 else 20))
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         st0 = streams[0]
         torch.cuda.synchronize()
+        roof_bytes = 0
         with torch.cuda.stream(st0):
-            for a, b in sev:
+            for j, (a, b) in enumerate(sev):
                 a.record(st0)
-                world.trace_frames([cam] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames(cams_of(j * G, G), prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 b.record(st0)
+                roof_bytes += sum(algo_cam[(j * G + f) % P] for f in range(G))
         st0.synchronize()
-        kernel_ms_avg = sum(a.elapsed_time(b) for a, b in sev) / reps
+        kernel_ms_sum = sum(a.elapsed_time(b) for a, b in sev)
+        kernel_ms_avg = kernel_ms_sum / reps
 
     if rank == 0 and multi and not args.no_gather:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
-        lastf = args.steps - 1
-        frame_full = svo.partition.deinterleave([g[lastf % G] for g in gathered[(lastf // G) % S]], ih, BAND)
+        frame_full = svo.partition.deinterleave(last_gathered, ih, BAND)
         assert frame_full.shape[0] == ih
-        # untimed self-check: the gathered, de-interleaved frame equals a single-GPU trace of the whole image
+        # untimed self-check (mandatory): the gathered, de-interleaved frame equals a single-GPU trace of the whole image
         whole = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
         whole_packed = torch.empty((ih, iw, prec), dtype=torch.uint8, device=dev)
-        world.trace(cam, prm, (0, 0, iw, ih), whole.data_ptr(), stream)
+        world.trace(path[lastf % P], prm, (0, 0, iw, ih), whole.data_ptr(), stream)
         svo.gbuffer_pack(whole.data_ptr(), whole_packed.data_ptr(), ih * iw, stream)
         torch.cuda.synchronize()
         if not torch.equal(whole_packed.cpu(), frame_full.cpu()):
             raise SystemExit("bench.py: gathered multi-GPU frame differs from the single-GPU frame")
 
-    result = None
     if rank == 0:
-        mrays = rays_frame * args.steps / elapsed / 1e6
+        rays_total = rays_of(args.steps)
+        mrays = rays_total / elapsed / 1e6
         result = {
             "metric": "Mrays/s (primary+shadow) at 1920x1080, depth-12 SVO",
             "value": round(mrays, 3),
@@ -321,50 +526,71 @@ def main():
             "config": {
                 "workload": args.workload,
                 "image": [iw, ih], "grid": [gw, gh, gd], "depth_per_chunk": depth, "chunksize": 128,
-                "shadow_rays": bool(shadow), "rays_per_frame": rays_frame,
+                "shadow_rays": bool(shadow), "rays_per_frame": round(rays_total / args.steps, 1),
+                "camera_path": {"kind": args.camera_path, "cameras": P, "rays_per_frame_min": min(rays_cam), "rays_per_frame_max": max(rays_cam),
+                                "note": "frame i is seen by camera i mod P; camera 0 = SURVEY §8d view (eye on the chunk seam), the others off the voxel lattice, the last one the grazing view"},
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
                 "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
-                "kernel": args.kernel, "launches_in_flight": S, "frames_per_launch": G, "frames_in_flight": S * G, "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather), "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
-                "world_generate_s": round(t_gen, 2), "world_upload_s": round(t_up, 2),
+                "kernel": args.kernel, "launches_in_flight": S, "frames_per_launch": G, "frames_in_flight": S * G,
+                "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather),
+                "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
+                "ranks_seen": ranks_seen, "devices": devices,
+                "launcher": "self-spawned" if os.environ.get("SVO_BENCH_SPAWNED") else ("external" if "WORLD_SIZE" in os.environ else "single process"),
+                "world_generate_s": round(t_gen, 2), "world_generate_threads": gen_threads, "world_upload_s": round(t_up, 2),
             },
         }
+        if diag:
+            result["diagnostics"] = diag
         if not multi and not args.emulate_share:
-            achieved = algo_bytes * G / (kernel_ms_avg * 1e-3) / 1e9      # one launch marches G frames
-            traffic = None
-            valu = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, if profiled
+            achieved = roof_bytes / (kernel_ms_sum * 1e-3) / 1e9         # algorithmic bytes of the timed launches / their durations
+            algo_total = sum(algo_cam[i % P] for i in range(args.steps))
+            prof = {}
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived figures of an earlier profiled run, if any
             if os.path.exists(tpath):
                 try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(args.workload, {}).get("hbm_bytes_per_frame")      # PMC passes run one frame per launch
-                    traffic = traffic * G if traffic else None
-                    valu = tj.get(args.workload, {}).get("valu_insts_per_frame")
+                    prof = json.load(open(tpath)).get(args.workload, {})
                 except Exception:
-                    traffic = None
+                    prof = {}
+            traffic = prof.get("fabric_bytes_per_frame", prof.get("hbm_bytes_per_frame"))
             result["roofline"] = {
                 "bound": "hbm", "kernel": "k_trace_stack" if args.kernel != "literal" else "k_trace_literal",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac_of_achievable_6300": round(achieved / HBM_STREAM_GBS, 5),
+                # PMC figures are NOT measured in this run: replayed from the committed profile of the same workload
+                "traffic": traffic * G if traffic else None,
+                "traffic_kind": "L2-miss fabric bytes per launch (FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, so an upper bound on HBM bytes)",
+                "traffic_source": prof.get("source", "none") + " (replayed, not measured in this run)",
+                "l2_hit_rate": prof.get("l2_hit_rate"),
                 # the same bytes over whole-job time: what the overlapped launches deliver together
-                "achieved_throughput": round(algo_bytes * args.steps / elapsed / 1e9, 2),
-                "frac_throughput": round(algo_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                "algorithmic_bytes_per_launch": int(algo_bytes) * G, "frames_per_launch": G,
-                "bytes_per_ray": round(algo_bytes / rays_frame, 2),
-                "kernel_ms_avg": round(kernel_ms_avg, 5),
+                "achieved_throughput": round(algo_total / elapsed / 1e9, 2),
+                "frac_throughput": round(algo_total / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                "algorithmic_bytes_per_launch": int(roof_bytes // reps), "frames_per_launch": G,
+                "bytes_per_ray": round(sum(algo_cam) / sum(rays_cam), 2),
+                "kernel_ms_avg": round(kernel_ms_avg, 5), "kernel_launches_timed": reps,
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
-                "counters": counters_sum,
+                "counters_all_path_cameras": counters_sum,
             }
-            if valu:
-                # what the march is really bound by: a wave64 VALU instruction holds one of the
-                # 1024 SIMDs for 4 cycles; profiled instruction count per launch over this run's time per frame
+            if prof.get("valu_insts_per_frame"):
+                # VALU issue: cycles per wave64 instruction per SIMD measured by scripts/microbench/valu_issue.hip
+                cyc = float(prof.get("valu_cycles_per_inst", 2.45))
                 simd_cycles = 1024 * 2.4e9 * (elapsed / args.steps)
-                result["roofline"]["valu_issue"] = {"insts_per_frame": int(valu), "frac_of_issue_slots": round(valu * 4 / simd_cycles, 4),
-                                                    "note": "SQ_INSTS_VALU per one-frame launch from profiles/ (PMC pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x s per frame)"}
+                result["roofline"]["valu_issue"] = {
+                    "insts_per_frame": int(prof["valu_insts_per_frame"]), "cycles_per_inst": cyc,
+                    "frac_of_issue_slots": round(prof["valu_insts_per_frame"] * cyc / simd_cycles, 4),
+                    "source": prof.get("source", "") + " (replayed)",
+                    "note": "SQ_INSTS_VALU per one-frame launch x measured cycles per wave64 VALU instruction / (1024 SIMDs x 2.4 GHz x s per frame)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
                 O = ob.OracleWorld.from_chunks([world.chunk(i, copy=False) for i in range(n)], gw, gh, gd, 128)
                 cores = os.cpu_count() or 1
+                # the sample: the last timed launch's last frame that an off-lattice camera saw (any frame of a fixed path)
+                sub = last_sub
+                while P > 1 and sub > 0 and (lastf - (last_sub - sub)) % P == 0:
+                    sub -= 1
+                fidx = lastf - (last_sub - sub)
+                cam = path[fidx % P]
                 if args.cpu_crop:
                     c = args.cpu_crop
                     rect = ((iw - c) // 2, (ih - c) // 2, c, c)
@@ -375,15 +601,23 @@ def main():
                 dt = time.perf_counter() - t0
                 result["cpu_baseline"] = {
                     "value": round(O.last_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                    "sample": f"{rect[2]}x{rect[3]} pixels of the same frame (rect x0={rect[0]}, y0={rect[1]}), "
+                    "sample": f"path camera {fidx % P} (eye x = {cam.eye[0]:.3f}), {rect[2]}x{rect[3]} pixels (rect x0={rect[0]}, y0={rect[1]}), "
                               f"{O.last_rays} rays incl. shadow, {dt:.2f} s wall on {cores} threads, oracle/svo_oracle.c -O2",
                 }
                 # parity of the timed product output against the oracle on that sample
-                lastf = args.steps - 1
-                got = bufs[(lastf // G) % S][lastf % G].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+                got = last_out[sub].cpu().numpy().view(svo.HIT_DTYPE).reshape(ih, iw)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
                 same = all(np.array_equal(got[f], ref[f]) for f in ("flags", "material", "chunk", "node", "cell")) and \
                     np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
                 result["cpu_baseline"]["parity_with_gpu"] = bool(same)
+                result["cpu_baseline"]["parity_camera_off_lattice"] = bool(P > 1 and fidx % P != 0)
+                # one thread, centred 256x256 crop of the same frame
+                c1 = 256
+                r1 = ((iw - c1) // 2, (ih - c1) // 2, c1, c1)
+                t0 = time.perf_counter()
+                O.trace_image(cam, rect=r1, params=ob.make_params(shadow=shadow), threads=1)
+                dt1 = time.perf_counter() - t0
+                result["cpu_baseline"]["single_thread"] = {"value": round(O.last_rays / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                                                           "sample": f"centred {c1}x{c1} crop of the same frame, {O.last_rays} rays, {dt1:.2f} s"}
         print(json.dumps(result), flush=True)
 
     world.destroy()

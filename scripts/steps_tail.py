@@ -8,6 +8,10 @@ W = svo.World.generate(4, 1, 4, 128, 12); W.upload(0)
 cam = svo.default_camera(4, 4, 128, 1920, 1080)
 if os.environ.get("SVO_BENCH_EYE_DX"):
     cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
+if os.environ.get("SVO_PATH_CAM"):                      # camera k of bench.py's path
+    sys.path.insert(0, ROOT)
+    import bench
+    cam = bench.camera_path(svo, "c3_1080p_depth12_4x1x4_shadow", 4, 4, 1920, 1080)[int(os.environ["SVO_PATH_CAM"])]
 g, c = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL, counters=True)
 c = c.astype(np.int64)
 steps = (c[..., 3] + c[..., 1] + c[..., 2]).reshape(1080, 1920)

@@ -10,6 +10,10 @@ W = svo.World.generate(4, 1, 4, 128, depth); W.upload(0)
 cam = svo.default_camera(4, 4, 128, 1920, 1080)
 if os.environ.get("SVO_BENCH_EYE_DX"):
     cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
+if os.environ.get("SVO_PATH_CAM"):                      # camera k of bench.py's path
+    sys.path.insert(0, ROOT)
+    import bench
+    cam = bench.camera_path(svo, "c3_1080p_depth12_4x1x4_shadow", 4, 4, 1920, 1080)[int(os.environ["SVO_PATH_CAM"])]
 nblk = 256 * 32
 out = svo.DeviceBuffer(F * 1920 * 1080 * 32)
 for rep in range(3):
