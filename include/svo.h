@@ -35,7 +35,11 @@
  *   - one handle may be used by one host thread at a time; different handles are independent;
  *   - svo_trace* launches of one world may overlap on different streams (frames in flight); each
  *     launch owns a private work-cursor slot from a 64-entry ring, and a launch that comes round
- *     to a slot still in use is ordered on the device behind that earlier launch.
+ *     to a slot still in use is ordered on the device behind that earlier launch;
+ *   - svo_world_update / svo_world_shift / svo_world_upload are ordered behind every launch issued
+ *     before them on any stream (they drain the device before touching HBM, as World::modify is
+ *     ordered on the GL queue) and have completed when they return: launches issued afterwards see
+ *     the new world, launches issued before saw the old one, none sees a mixture.
  *
  * Semantics are those of the reference's CPU march (src/Traverse.cpp): EPS = 1/8192, step caps
  * 1000/1000/1000, closed-box containment, restart-from-root descent.  The extra per-hit outputs
@@ -152,7 +156,10 @@ enum {
     SVO_HIT_FLAG      = 1u << 0,    /* primary ray hit a voxel */
     SVO_SHADOW_TRACED = 1u << 1,    /* a shadow ray was cast from this hit */
     SVO_SHADOWED      = 1u << 2,    /* ... and it hit something */
-    SVO_ERR_FLAG      = 1u << 15    /* traversal met a malformed node (never on validated worlds) */
+    SVO_ERR_FLAG      = 1u << 15    /* runaway ray: given up after 2^22 march steps of the kernel's own counting (only rays that
+                                       creep through all three nested loops of the reference get there; the stack kernel
+                                       takes creeping stretches in closed form and finishes rays the literal kernel gives
+                                       up).  A primary ray is then recorded as a miss, a shadow ray as "traced, not occluded" */
 };
 #define SVO_CELL_NONE 0xFFu         /* hit a LEAF node, not a brick cell */
 
@@ -260,8 +267,8 @@ int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);
 
 /* ---- packed G-buffer (8 bytes / pixel) for the multi-GPU gather ------------------------------------------
- * { float t; uint32 w } with w = material (bits 0-15) | flags & 0xFF (bits 16-23) | normal code (bits 24-30):
- * per axis 2 bits (0: -, 1: 0, 2: +) in bits 24-29, bit 30 = NaN normal.  cubeNormal only ever yields
+ * { float t; uint32 w } with w = material (bits 0-15) | flags & 0xFF (bits 16-23) | normal code (bits 24-30) |
+ * SVO_ERR_FLAG (bit 31): per axis 2 bits (0: -, 1: 0, 2: +) in bits 24-29, bit 30 = NaN normal.  cubeNormal only ever yields
  * normalize(ivec3 in {-1,0,1}^3) (shaders/Chunkmarch.glsl:128-136), so t, normal, material and flags survive the
  * round trip bit for bit; the parity ids (chunk, node, cell) are not carried (unpack zeroes them). */
 int svo_gbuffer_pack(const svo_hit *gbuffer_dev, uint64_t *packed_dev, int64_t n, void *stream);

@@ -401,20 +401,27 @@ static int generate_world_device_impl(int device, int w, int h, int d, int chunk
         int nthreads = tp.threads > 0 ? tp.threads : (int)std::thread::hardware_concurrency();
         nthreads = std::max(1, std::min<int>(nthreads, (int)chunks.size()));
         std::atomic<size_t> cursor{ 0 };
+        std::atomic<int> failed{ 0 };           // nothing may escape a std::thread (std::terminate): report after join
         auto worker = [&]() {
-            for (;;) {
-                const size_t i = cursor.fetch_add(1);
-                if (i >= chunks.size()) break;
-                ChunkPools &c = chunks[i];
-                const float hi[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
-                DirtyRange a, b;
-                fill_box(c, c.position, hi, (uint16_t)tp.water_material, a, b);
+            try {
+                for (;;) {
+                    const size_t i = cursor.fetch_add(1);
+                    if (i >= chunks.size()) break;
+                    ChunkPools &c = chunks[i];
+                    const float hi[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
+                    DirtyRange a, b;
+                    fill_box(c, c.position, hi, (uint16_t)tp.water_material, a, b);
+                }
+            } catch (...) {
+                failed.store(1);
+                cursor.store(chunks.size());
             }
         };
         std::vector<std::thread> pool;
         for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
         worker();
         for (auto &t : pool) t.join();
+        if (failed.load()) { set_error("svo_world_generate: out of host memory in the water fill"); return SVO_ERR_OUT_OF_MEMORY; }
     }
     return SVO_OK;
 }

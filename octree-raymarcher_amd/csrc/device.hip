@@ -220,8 +220,12 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
     classify_world(*w);
     if (w->device < 0) return SVO_OK;
 
-    // 2. refresh HBM
+    // 2. refresh HBM.  Launches of this world may still be in flight on the caller's streams (non-blocking streams are
+    //    not ordered against the copies below, and a march that reads a half-rewritten tree could follow a stale BRANCH
+    //    chain): like World::modify on the GL queue (src/World.cpp:268-274), the update is ordered behind everything
+    //    issued before it - the device is drained first.
     HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipDeviceSynchronize());
     DevChunk &e = w->table[(size_t)chunk];
     const bool tree_fits = c.tree.size() <= w->tree_slot[(size_t)chunk];
     const bool twig_fits = c.twig_count() <= w->twig_slot[(size_t)chunk];
@@ -313,10 +317,12 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
 static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const TraceArgs &A)
 {
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
-    const bool stack_ok = w->exact_geometry && w->max_levels <= 16;
+    // the stack kernel addresses nodes by a 32-bit byte offset into the tree pool: pools of 2^30 nodes and more (4 GiB;
+    // the benchmark world has 0.1 G nodes) are marched by the literal kernel
+    const bool stack_ok = w->exact_geometry && w->max_levels <= 16 && w->tree_pool_cap < (1ull << 30);
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
-        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry and depth <= 18"); return SVO_ERR_UNSUPPORTED; }
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, depth <= 18 and a tree pool below 2^30 nodes"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }

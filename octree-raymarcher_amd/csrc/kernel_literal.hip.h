@@ -87,8 +87,10 @@ __device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevC
     return false;
 }
 
+// `runaway` is set when the ray used up STEP_GUARD march steps (the kernels' bound on a single ray; the reference itself
+// would keep going): the caller flags the record with SVO_ERR_FLAG, as the stack kernel does.
 __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &tout, Voxel &vox, uint32_t &chunk,
-                                 LitCounters &cnt)
+                                 LitCounters &cnt, bool &runaway)
 {
     const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
     const V3 g = recip(beta);
@@ -98,7 +100,7 @@ __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &t
     if (!hit) return false;
     uint32_t guard = 0;
     for (int c = 0; c < A.cap_chunk; ++c) {
-        if (++guard > STEP_GUARD) return false;
+        if (++guard > STEP_GUARD) { runaway = true; return false; }
         const V3 p = alpha + beta * t;
         if (!inside(p, wlo, whi)) return false;
         const int ci = chunk_index(A, p);
@@ -114,6 +116,7 @@ __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &t
             chunk = (uint32_t)ci;
             return true;
         }
+        if (guard > STEP_GUARD) { runaway = true; return false; }      // the tree / brick march gave up, not the reference's caps
         t += escape(p, g, clo, chi) + A.eps;
     }
     return false;
@@ -142,19 +145,20 @@ __global__ __launch_bounds__(256) void k_trace_literal(TraceArgs A)
         float t = 0.0f;
         uint32_t chunk = 0;
         rays = 1;
-        if (lit_world(A, o, d, t, vox, chunk, cnt)) {
+        bool runaway = false;
+        if (lit_world(A, o, d, t, vox, chunk, cnt, runaway)) {
             const V3 point = o + d * (t - A.eps);
             const V3 n = cube_normal(point, vox.lo, vox.lo + vox.size, A.eps);
             uint32_t flags = SVO_HIT_FLAG;
             if (A.shadow) {
                 Voxel sv; float st; uint32_t sc;
-                const bool occluded = lit_world(A, point, ld3(A.sdir), st, sv, sc, cnt);
-                flags |= SVO_SHADOW_TRACED | (occluded ? SVO_SHADOWED : 0u);
+                const bool occluded = lit_world(A, point, ld3(A.sdir), st, sv, sc, cnt, runaway);
+                flags |= SVO_SHADOW_TRACED | (occluded ? SVO_SHADOWED : 0u) | (runaway ? (uint32_t)SVO_ERR_FLAG : 0u);
                 rays = 2;
             }
             store_hit(A.out, k, t, n, vox.material, flags, chunk, vox.node, vox.cell);
         } else {
-            store_miss(A.out, k, 0);
+            store_miss(A.out, k, runaway ? (uint32_t)SVO_ERR_FLAG : 0u);
         }
         if (A.counters) {
             uint4 c; c.x = cnt.node_words; c.y = cnt.brick_cells; c.z = cnt.chunk_descs; c.w = cnt.tree_steps;

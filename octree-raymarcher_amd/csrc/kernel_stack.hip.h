@@ -109,6 +109,12 @@ __device__ __forceinline__ uint32_t child_slot(int ux, int uy, int uz, int sh)
     const uint32_t bz = __builtin_amdgcn_ubfe((uint32_t)uz, (uint32_t)sh, 1u);
     return ((bz << 1) + by) * 2u + bx;
 }
+// node word at byte offset `boff` of the tree pool: scalar base + zero-extended 32-bit vector offset (one VGPR of address
+// instead of a 64-bit pointer per lane; the launch checks that the pool is smaller than 4 GiB)
+__device__ __forceinline__ uint32_t ld_node(const uint32_t *pool, uint32_t boff)
+{
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pool) + (size_t)boff);
+}
 // type == BRANCH (binary 10 in the top bits) as one signed comparison
 __device__ __forceinline__ bool is_branch(uint32_t word) { return (int32_t)word < (int32_t)0xC0000000; }
 
@@ -133,6 +139,51 @@ __device__ __forceinline__ FrameCam camera_reloaded(int f)
     return c;
 }
 
+// How far along the ray a + b*s (s >= 0) can brick marches go before one of them might see an occupied cell?
+// Asked for a run of tree steps over one TWIG node whose start points p_j = a + b*s_j all lie ON the brick's lower
+// face of axis k (p_j.k == bmin.k) with b.k < 0; every twigmarch(p_j, b, brick) (src/Traverse.cpp:50-72) then
+//  * only sees cells with coordinate 0 on axis k: p.k = p_j.k + b.k*t <= bmin.k for t >= 0, so p is in that layer or
+//    outside the brick (the march returns false);
+//  * takes pinned steps only, t += EPS (see the creep block), and ends once |b.k|*t exceeds half an ulp of bmin.k;
+//  * moves forward along the ray: on the other two axes the brick's corner is at least a brick edge away from 0
+//    (checked), so p - bmin is exact (Sterbenz), the truncated cell index is the cell p really lies in and no escape
+//    distance is negative.
+// Returns the smallest s at which the ray, widened by r/16 (>> the rounding of p, checked), touches an occupied cell of
+// that layer: +inf if it never does, -1 if a precondition fails.  Marches that stay below that parameter are misses,
+// however they end (leaving the brick, step cap, NaN).  r = voxel edge.
+#ifndef SVO_NEST_INLINE
+#define SVO_NEST_INLINE __noinline__
+#endif
+__device__ SVO_NEST_INLINE float brick_layer_first_touch(int k, V3 a, V3 b, V3 g, V3 bmin, float r, unsigned long long mask)
+{
+    // axis k is the pinned one; u, v = the other two (component selection by k, no indexed arrays)
+    const float ak = k == 0 ? a.x : k == 1 ? a.y : a.z, bk = k == 0 ? b.x : k == 1 ? b.y : b.z, mk_ = k == 0 ? bmin.x : k == 1 ? bmin.y : bmin.z;
+    const float au = k == 0 ? a.y : k == 1 ? a.z : a.x, av = k == 0 ? a.z : k == 1 ? a.x : a.y;
+    const float gu = k == 0 ? g.y : k == 1 ? g.z : g.x, gv = k == 0 ? g.z : k == 1 ? g.x : g.y;
+    const float mu = k == 0 ? bmin.y : k == 1 ? bmin.z : bmin.x, mv = k == 0 ? bmin.z : k == 1 ? bmin.x : bmin.y;
+    const int su = k == 0 ? 4 : k == 1 ? 16 : 1, sv = k == 0 ? 16 : k == 1 ? 1 : 4;      // bit strides of u and v in the brick mask
+    const float delta = r * 0.0625f;
+    bool ok = (ak == mk_) & (bk < 0.0f);
+    ok &= (mu >= 4.0f * r) & (mv >= 4.0f * r) & (delta >= (fabsf(mu) + fabsf(mv) + 8.0f * r) * 0x1p-21f);
+    ok = ok && fabsf(gu) < 1.0e30f && fabsf(gv) < 1.0e30f;                // 1/b finite on both axes (no 0 * inf below)
+    if (!ok) return -1.0f;
+    const float u0 = au - mu, v0 = av - mv;
+    float first = __uint_as_float(0x7F800000u);
+    bool clean = true;
+    for (int cv = 0; cv < 4; ++cv) {
+        const float va = ((float)cv * r - delta - v0) * gv, vb = ((float)(cv + 1) * r + delta - v0) * gv;
+        const float v_in = fminf(va, vb), v_out = fmaxf(va, vb);
+        for (int cu = 0; cu < 4; ++cu) {
+            const bool occupied = (mask >> (cu * su + cv * sv)) & 1ull;
+            const float ua = ((float)cu * r - delta - u0) * gu, ub = ((float)(cu + 1) * r + delta - u0) * gu;
+            const float s_in = fmaxf(fmaxf(fminf(ua, ub), v_in), 0.0f), s_out = fminf(fmaxf(ua, ub), v_out);
+            clean &= (s_in == s_in) & (s_out == s_out);               // NaN cannot happen with finite operands; stay on the safe side
+            first = (occupied & (s_in <= s_out)) ? fminf(first, s_in) : first;
+        }
+    }
+    return clean ? first * (1.0f - 0x1p-18f) : -1.0f;                  // the slab parameters carry a few ulps of their own
+}
+
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
@@ -143,7 +194,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
-    unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0;   // block runs, lane-steps taken in it (this lane), rounds
+    unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
 #endif
 
     const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
@@ -171,8 +222,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 
     // ---- lane state ------------------------------------------------------------------------
     int mode = M_DONE;
-    bool is_shadow = false;
-    int outk = 0;
+    int outk = 0;                   // output record of the ray; bit 31 set: the lane marches that pixel's shadow ray
     V3 alpha = mk(0, 0, 0), beta = mk(0, 0, 1), g = mk(0, 0, 0);
     float tw = 0.0f;                // chunkmarch's t (src/Traverse.cpp:135)
     int cw = 0;
@@ -181,20 +231,20 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     // tested against the box [Blo, Blo+Bsize] and located on a lattice of pitch `res` anchored at Blo.
     // Entering a brick swaps the frame (and parks the tree level's t / counter); leaving swaps it back.
     V3 O = mk(0, 0, 0), Blo = mk(0, 0, 0);
-    float Bsize = 0.0f, res = 1.0f, inv_res = 1.0f, t = 0.0f;
-    int cnt = 0, cap = 0;              // step counter of the level and its limit (A.cap_tree / A.cap_twig)
+    // (the box edge, 1/res and the step cap follow from mode and res: chunk edge / 4 voxels, A.cap_tree / A.cap_twig)
+    float res = 1.0f, t = 0.0f;
+    int cnt = 0;                    // step counter of the level; in M_HIT: the brick cell that was hit (or SVO_CELL_NONE: a LEAF)
     float tt_saved = 0.0f;
     int it_saved = 0;
     // chunk
     V3 clo = mk(0, 0, 0);
-    const uint32_t *tree = A.tree;
+    uint32_t tree_b = 0;            // byte offset of the chunk's node 0 in the tree pool
     uint32_t twig_off = 0;
     int levels = 0, ci = -1;
     // descent cache: cell coordinates of the last tree step and the level of the node it ended at
     int pux = 0, puy = 0, puz = 0, valid = 0;
     // brick
     unsigned long long bmask = 0;
-    uint32_t hitc = SVO_CELL_NONE;  // M_HIT: which brick cell (or none: LEAF)
     // creeping rays: |creepn| = consecutive advances of this ray by less than 2 EPS (kept across level changes: a ray pinned
     // on a chunk face creeps at every level); > 0 only while the cell located last is known to be empty (creep block armed)
     int creepn = 0;
@@ -274,12 +324,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const int slot = tile_next + rank;
                 const int k = __float_as_int(tile_ray[10][slot]);
                 if (k >= 0) {
-                    outk = k;
+                    outk = k;                               // (bit 31 clear: primary ray)
                     alpha = mk(tile_ray[0][slot], tile_ray[1][slot], tile_ray[2][slot]);
                     beta = mk(tile_ray[3][slot], tile_ray[4][slot], tile_ray[5][slot]);
                     g = mk(tile_ray[6][slot], tile_ray[7][slot], tile_ray[8][slot]);
                     tw = tile_ray[9][slot];
-                    is_shadow = false;
                     cw = 0; guard = 0; creepn = 0;
                     mode = M_WORLD;
                 }
@@ -305,7 +354,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
         if (mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD) {     // runaway ray: give up, flag it
-            if (is_shadow) store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
+            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
             else store_miss(A.out, outk, SVO_ERR_FLAG);
             mode = M_DONE;
         }
@@ -332,19 +381,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     clo = ld3(ch.bmin);
                     miss = !inside(p, clo, clo + csize);
                     if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
-                        tree = A.tree + ch.tree_off;
+                        tree_b = (uint32_t)ch.tree_off << 2;
                         twig_off = (uint32_t)ch.twig_off;
                         levels = (int)ch.levels;
                         O = p; t = 0.0f; cnt = 0;
-                        Blo = clo; Bsize = csize;
+                        Blo = clo;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
-                        inv_res = recip_pow2(res); cap = A.cap_tree;
                         mode = M_TREE;
                     }
                 }
             }
             if (miss) {
-                if (!is_shadow) store_miss(A.out, outk, 0);
+                if (outk >= 0) store_miss(A.out, outk, 0);
                 mode = M_DONE;                          // shadow miss: record already says "traced, lit"
             }
         }
@@ -355,6 +403,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
+            const float Bsize = twig ? res * 4.0f : csize, inv_res = recip_pow2(res);
+            const int cap = twig ? A.cap_twig : A.cap_tree;
             const int crept = creepn < 0 ? -creepn : creepn;
             creepn = -crept;                                        // disarmed unless this step advances (see the creep block)
             bool leave = cnt >= cap;
@@ -394,7 +444,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         node = stk[usable - 1][lane] + child_slot(ux, uy, uz, sh);
                         --sh;
                     }
-                    uint32_t word = tree[node];
+                    uint32_t word = ld_node(A.tree, tree_b + (node << 2));
                     // No level test: svo_world_create / svo_world_update reject a reachable BRANCH below level depth-2
                     // (validate_chunk), so the walk ends at or above the last level.
                     while (is_branch(word)) {
@@ -402,7 +452,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         stk[levels - 1 - sh][lane] = base;
                         node = base + child_slot(ux, uy, uz, sh);
                         --sh;
-                        word = tree[node];
+                        word = ld_node(A.tree, tree_b + (node << 2));
                     }
                     valid = levels - 1 - sh; pux = ux; puy = uy; puz = uz;
                     low = (1 << (sh + 1)) - 1;                      // the node spans 2^(levels - level) cells
@@ -429,9 +479,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     t = tt_saved + e;
                     cnt = it_saved;
                     O = alpha + beta * tw;                          // the chunk march's p (src/Traverse.cpp:144,158)
-                    Blo = clo; Bsize = csize;
+                    Blo = clo;
                     res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
-                    inv_res = recip_pow2(res); cap = A.cap_tree;
                     mode = M_TREE;
                 } else {                                            // out of the chunk
                     tw += e;
@@ -443,21 +492,19 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 tt_saved = t; it_saved = cnt;
                 O = p; t = 0.0f; cnt = 0;
                 Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
-                Bsize = res * (float)(low + 1);
-                res = Bsize * 0.25f;                                // leafsize = size / 4, exact
-                inv_res = recip_pow2(res); cap = A.cap_twig;
+                res = (res * (float)(low + 1)) * 0.25f;             // leafsize = node size / 4, exact
                 mode = M_TWIG;
             }
             if (what == S_HIT_LEAF) {
                 tw = tw + (t - eps);                                // src/Traverse.cpp:93,160
-                hitc = SVO_CELL_NONE;
+                cnt = (int)SVO_CELL_NONE;
                 mode = M_HIT;
             }
             if (what == S_HIT_CELL) {
                 float sdist = t;                                    // src/Traverse.cpp:63
                 sdist += tt_saved;                                  // :101
                 tw = tw + sdist;                                    // :160
-                hitc = payload;
+                cnt = (int)payload;
                 mode = M_HIT;
             }
         }
@@ -475,18 +522,37 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      the reference's escape is max((lo.a-q.a)*g.a, (hi.a-q.a)*g.a) = max(-0, negative) = -0 on axis a and
         //      >= +0 or -0 on the others, its glm::min chain yields -0, and the step is t += (-0 + EPS) = EPS, counters
         //      included.  Anything else hands the lane back to the general step, which recomputes from the same state.
+        //      Nested creeps: a ray pinned on the lower face of a TWIG node's box creeps at the tree level (EPS per tree
+        //      step) and, inside every one of those steps, through the brick (twigmarch runs until p drops off the face,
+        //      returns false, src/Traverse.cpp:97-105): quadratically many steps.  A lane that has just entered a brick
+        //      with a creeping history asks whether the whole run of tree steps over this node consists of such misses
+        //      (brick_layer_first_touch bounds how far they can go); that run is taken at once, exactly like a run over an EMPTY node.
         {
             const bool cr = creepn > 0 && (mode == M_TREE || mode == M_TWIG);
+#ifdef SVO_NO_NEST
+            const bool ent = false;
+#else
+            const bool ent = mode == M_TWIG && cnt == 0 && t == 0.0f && creepn <= -4 * SVO_CREEP_SERIOUS;     // fresh in a brick after a long creep
+#endif
             const unsigned long long crm = __ballot(cr);
-            if (crm != 0ull && eps_pow2 && (__ballot(cr && creepn >= SVO_CREEP_SERIOUS) != 0ull || __popcll(crm) >= SVO_CREEP_LANES)) {
-                const bool twig = mode == M_TWIG;
+            if (eps_pow2 && (__ballot(ent) != 0ull || (crm != 0ull && (__ballot(cr && creepn >= SVO_CREEP_SERIOUS) != 0ull || __popcll(crm) >= SVO_CREEP_LANES)))) {
+                const bool twig = mode == M_TWIG && !ent;           // closed form inside a brick cell
+                const float Bsize = mode == M_TWIG ? res * 4.0f : csize, inv_res = recip_pow2(res);
+                const int cap = mode == M_TWIG ? A.cap_twig : A.cap_tree;
                 const float finite_max = __uint_as_float(0x7F7FFFFFu);
-                bool go = cr && (fabsf(g.x) <= finite_max) && (fabsf(g.y) <= finite_max) && (fabsf(g.z) <= finite_max);
-                const V3 q0 = O + beta * t;                         // where the next reference step starts
+                bool go = (cr || ent) && (fabsf(g.x) <= finite_max) && (fabsf(g.y) <= finite_max) && (fabsf(g.z) <= finite_max);
+                // the frame the steps are taken in: the lane's own, or (ent) the tree level that entered the brick
+                const V3 fO = ent ? alpha + beta * tw : O;
+                const float ft = ent ? tt_saved : t;
+                const int kmax = ent ? A.cap_tree - it_saved + 1 : min(cap - cnt, (int)(STEP_GUARD - guard));
+                const V3 q0 = fO + beta * ft;                       // where the next reference step starts
                 V3 lo;
                 float fvx = 0.0f, fvy = 0.0f, fvz = 0.0f;            // brick: the cell's lattice coordinates as floats
                 float size;
-                if (!twig) {                                        // the EMPTY node located by the last tree step
+                if (ent) {                                          // the TWIG node's box == the brick frame
+                    lo = Blo; size = Bsize;
+                    go &= (q0.x == O.x) & (q0.y == O.y) & (q0.z == O.z);
+                } else if (!twig) {                                 // the EMPTY node located by the last tree step
                     const int low = (1 << (levels - valid)) - 1;
                     lo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
                     size = res * (float)(low + 1);
@@ -502,7 +568,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const V3 hi = lo + size;
                 // the next step itself must be a pinned one: (1) and (2) at q0
                 go &= (q0.x >= lo.x) & (q0.y >= lo.y) & (q0.z >= lo.z) & (q0.x < hi.x) & (q0.y < hi.y) & (q0.z < hi.z);
-                go &= ((beta.x < 0.0f) & (q0.x == lo.x)) | ((beta.y < 0.0f) & (q0.y == lo.y)) | ((beta.z < 0.0f) & (q0.z == lo.z));
+                const bool px = (beta.x < 0.0f) & (q0.x == lo.x), py = (beta.y < 0.0f) & (q0.y == lo.y), pz = (beta.z < 0.0f) & (q0.z == lo.z);
+                go &= px | py | pz;
 #ifdef SVO_STACK_TIMING
                 ++n_creep_runs;
 #endif
@@ -513,8 +580,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 // equals t_0 + k*EPS without rounding.  K is found by bit descent - 14 probes instead of K rounds -
                 // and the K steps are taken at once.
                 int K = 0;
-                const int kmax = min(cap - cnt, (int)(STEP_GUARD - guard));
-                const uint32_t t0b = __float_as_uint(t);
+#ifdef SVO_STACK_TIMING
+                unsigned n_dbg_e = 0;
+#endif
+                const uint32_t t0b = __float_as_uint(ft);
                 const int e_eps = (int)(__float_as_uint(eps) >> 23);
                 bool up = true;                                     // first double the probe (short creeps end here), then descend
                 for (int b = 1; b > 0;) {
@@ -522,12 +591,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     ++n_creep_rounds;
 #endif
                     const int cand = up ? b : K + b;
-                    const float tk = t + (float)(cand - 1) * eps;   // position before the cand-th step
-                    const float tn = t + (float)cand * eps;         // parameter after it: must be exact
+                    const float tk = ft + (float)(cand - 1) * eps;  // position before the cand-th step
+                    const float tn = ft + (float)cand * eps;        // parameter after it: must be exact
                     const int e_n = (int)(__float_as_uint(tn) >> 23), shift = e_n - (int)(t0b >> 23);
                     bool ok = go && cand <= kmax && e_n - 23 <= e_eps && tn < __uint_as_float(0x7F800000u);
                     ok = ok && (t0b == 0u || (t0b >= 0x00800000u && shift < 24 && (((t0b & 0x007FFFFFu) | 0x00800000u) & ((1u << shift) - 1u)) == 0u));
-                    const V3 q = O + beta * tk;
+                    const V3 q = fO + beta * tk;
                     ok &= (q.x >= lo.x) & (q.y >= lo.y) & (q.z >= lo.z) & (q.x < hi.x) & (q.y < hi.y) & (q.z < hi.z);
                     if (twig) {                                     // the reference's own cell index must agree (truncation of a rounded difference)
                         const float fx = (q.x - Blo.x) * inv_res, fy = (q.y - Blo.y) * inv_res, fz = (q.z - Blo.z) * inv_res;
@@ -539,20 +608,58 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     else if (b >= (1 << 13)) { up = false; b >>= 1; }
                     else b <<= 1;
                 }
-                if (K > 0) {
+                if (ent) {
+                    // K tree steps over this TWIG node, each "brick march misses, t += EPS": only if every one of those
+                    // marches is a sure miss.  Then the brick is left as the reference leaves it after the K-th miss.
+                    bool sure = false;
+#ifdef SVO_STACK_TIMING
+                    n_dbg_e = 1u + (go ? 1u << 8 : 0u) + (K > 0 ? 1u << 16 : 0u);
+#endif
+                    if (K > 0) {
+                        // the marches of steps 0..K'-1 start at s <= (K'-1) EPS and last at most ulp/(2|b.k|) + EPS
+                        const int k = px ? 0 : py ? 1 : 2;
+                        const float bk = k == 0 ? Blo.x : k == 1 ? Blo.y : Blo.z, gk = k == 0 ? g.x : k == 1 ? g.y : g.z;
+                        const float tail = 0.5f * (__uint_as_float(__float_as_uint(fabsf(bk)) & 0x7F800000u) * 0x1p-23f) * fabsf(gk) + 2.0f * eps;
+                        const float room = brick_layer_first_touch(k, O, beta, g, Blo, res, bmask) - tail;
+                        if (room > 0.0f) {                          // (NaN and failed preconditions end here)
+                            const float steps = room * recip_pow2(eps);     // start points below `room`: s_j = j EPS < room
+                            const int allowed = steps >= 16384.0f ? 16384 : (int)steps + 1;
+                            K = K < allowed ? K : allowed;
+                            sure = true;
+                        }
+                    }
+#ifdef SVO_STACK_TIMING
+                    n_dbg_e += sure ? 1u << 24 : 0u;
+#endif
+                    if (sure) {
+                        t = tt_saved + (float)K * eps;
+                        cnt = it_saved + (K - 1);
+                        guard += (uint32_t)K; creepn -= K;
+                        O = fO;
+                        Blo = clo;
+                        res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
+                        mode = M_TREE;
+#ifdef SVO_STACK_TIMING
+                        n_creep_steps += K;
+#endif
+                    }
+                } else if (K > 0) {
                     t += (float)K * eps;                            // == K times t + (escape + EPS) with escape == -0
                     cnt += K; guard += (uint32_t)K; creepn += K;
 #ifdef SVO_STACK_TIMING
                     n_creep_steps += K;
 #endif
                 }
+#ifdef SVO_STACK_TIMING
+                for (int sh8 = 0; sh8 < 32; sh8 += 8) n_dbg += (unsigned)__popcll(__ballot((n_dbg_e >> sh8) & 1u)) << sh8;
+#endif
             }
         }
 
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
-        if (mode == M_HIT && is_shadow) {
-            store_flags(A.out, outk, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED);
+        if (mode == M_HIT && outk < 0) {
+            store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED);
             mode = M_DONE;
         }
         if (run_hit && mode == M_HIT) {
@@ -561,7 +668,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             const uint32_t node = valid > 0
                 ? stk[valid - 1][lane] + (uint32_t)(((pux >> sh) & 1) | (((puy >> sh) & 1) << 1) | (((puz >> sh) & 1) << 2))
                 : 0u;
-            const uint32_t word = tree[node];
+            const uint32_t word = ld_node(A.tree, tree_b + (node << 2));
+            const uint32_t hitc = (uint32_t)cnt;                    // which brick cell (or SVO_CELL_NONE: a LEAF)
             V3 vlo;
             float vsize;
             uint32_t material;
@@ -582,7 +690,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             mode = M_DONE;
             if (A.shadow) {                             // the lane becomes its own shadow ray
                 alpha = point; beta = sdir; g = sg;
-                is_shadow = true;
+                outk |= (int)0x80000000;
                 tw = 0.0f; cw = 0; guard = 0; creepn = 0;
                 bool hit = true;
                 if (!inside(alpha, wlo, whi)) tw = enter(alpha, beta, wlo, whi, hit) + eps;
@@ -601,7 +709,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
         reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 1] = e;
-        uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = 0;
+        uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = n_dbg;
         reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 2] = f;
     }
 #endif

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_gbuffer_pack(const uint4 *in, uint2 *ou
     const uint32_t code = nan ? (1u << 6) : (axis_code(nx) | (axis_code(ny) << 2) | (axis_code(nz) << 4));
     uint2 o;
     o.x = r0.x;
-    o.y = (r1.x & 0xFFFFu) | (((r1.x >> 16) & 0xFFu) << 16) | (code << 24);
+    const uint32_t flags = r1.x >> 16;
+    o.y = (r1.x & 0xFFFFu) | ((flags & 0xFFu) << 16) | (code << 24) | ((flags & SVO_ERR_FLAG) ? 1u << 31 : 0u);
     out[k] = o;
 }
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_unpack(const uint2 *in, uint4 *
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const uint2 p = in[k];
-    const uint32_t code = p.y >> 24, flags = (p.y >> 16) & 0xFFu;
+    const uint32_t code = (p.y >> 24) & 0x7Fu, flags = ((p.y >> 16) & 0xFFu) | ((p.y >> 31) ? (uint32_t)SVO_ERR_FLAG : 0u);
     float nx = 0.0f, ny = 0.0f, nz = 0.0f;
     if (flags & SVO_HIT_FLAG) {
         if (code & (1u << 6)) {

@@ -316,7 +316,9 @@ int generate_world(int w, int h, int d, int chunksize, const int ccm[3], const T
     nthreads = std::max(1, std::min(nthreads, columns));
 
     std::atomic<int> cursor{ 0 };
+    std::atomic<int> failed{ 0 };               // a worker ran out of memory: nothing may escape a std::thread (std::terminate)
     auto worker = [&]() {
+        try {
         HeightPyramid pyr;
         for (;;) {
             const int col = cursor.fetch_add(1);
@@ -340,12 +342,16 @@ int generate_world(int w, int h, int d, int chunksize, const int ccm[3], const T
                 }
             }
         }
+        } catch (...) {
+            failed.store(1);
+            cursor.store(columns);              // the other workers stop at their next column
+        }
     };
     std::vector<std::thread> pool;
     for (int i = 1; i < nthreads; ++i) pool.emplace_back(worker);
     worker();
     for (auto &t : pool) t.join();
-    return 0;
+    return failed.load() ? -1 : 0;
 }
 
 } // namespace svo

@@ -124,7 +124,11 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
             const int rc = generate_world_device(tp->build_device_plus1 - 1, w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
             if (rc != SVO_OK) { delete world; return rc; }
         } else {
-            generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
+            if (generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks) != 0) {
+                delete world;
+                set_error("svo_world_generate: out of host memory in a generator thread");
+                return SVO_ERR_OUT_OF_MEMORY;
+            }
         }
         world->terrain = p;
         world->has_terrain = true;

@@ -33,7 +33,7 @@ it = c[:, 2].astype(np.int64)
 print("iters  p50 %d p99 %d max %d   us/iter p50 %.2f" % (np.percentile(it, 50), np.percentile(it, 99), it.max(), np.median((en - st) / it)))
 late = np.argsort(en)[-8:]
 for i in late:
-    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d lane0-steps %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1]))
+    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d lane0-steps %d dbg ent %d go %d K>0 %d sure %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1], f[i, 3] & 255, (f[i, 3] >> 8) & 255, (f[i, 3] >> 16) & 255, f[i, 3] >> 24))
 for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
     print("t=%5d us running waves: %d" % (t, ((st <= t) & (en > t)).sum()))
 

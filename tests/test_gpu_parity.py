@@ -405,3 +405,71 @@ def test_fuzz_one_million_adversarial_rays(svo, oracle):
                 got = W.chunkmarch(o, d, shadow=True, kernel=k, light_dir=light)
                 assert_gbuffer_equal(got, want, f"fuzz {c} kernel {k} light {light}")
         W.destroy()
+
+
+def test_runaway_guard_flags_both_kernels(svo, oracle, worlds):
+    """A ray pinned on a chunk face creeps in chunkmarch, treemarch and twigmarch at once: with caps 1000/1000/6 it takes
+    7 M steps, more than the kernels' per-ray bound of 2^22 steps of their own counting.  A kernel that gives such a ray
+    up records a miss flagged SVO_ERR_FLAG (the reference, and the oracle, walk on to a plain miss); the packed record
+    keeps the flag.  With EPS a power of two the stack kernel takes the creeping stretches in closed form and may finish
+    the ray - then exactly as the oracle does; with another EPS both kernels walk it step by step and both give up."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    o = np.array([[128.0, 64.0, 32.0], [128.0, 61.67112731933594, 45.62421417236328], [100.3, 120.0, 77.7]], np.float32)
+    d = np.array([[-3.2018779165809974e-06, -0.9999757409095764, -0.006965192500501871],
+                  [-2.4640150968480157e-06, -0.2718605697154999, -0.9623366594314575], [0.3, -0.9, 0.1]], np.float32)
+    caps = (1000, 1000, 6)
+    for eps in (0.0, 1.0e-4):
+        want, wc = O.trace_rays(o, d, params=oracle.make_params(caps=caps, eps=eps), counters=True, threads=3)
+        steps = wc[:, 1].astype(np.int64) + wc[:, 2] + wc[:, 3]
+        assert np.all(steps[:2] > 6_000_000) and np.all((want["flags"][:2] & 1) == 0) and steps[2] < 1000
+        got = {}
+        for k in KERNELS:
+            g = W.chunkmarch(o, d, kernel=_kid(svo, k), caps=caps, eps=eps)
+            gave_up = g["flags"][:2] == svo.ERR_FLAG
+            if k == "literal" or eps != 0.0:
+                assert np.all(gave_up), f"{k}: runaway rays must be misses flagged SVO_ERR_FLAG"
+            assert np.all(gave_up | (g["flags"][:2] == 0)), f"{k}: a runaway ray is given up or finished like the oracle (a miss)"
+            assert np.all(g["t"][:2] == 0) and np.all(g["material"][:2] == 0)
+            assert_gbuffer_equal(g[2:], want[2:], f"ordinary ray beside the runaway ones/{k}")
+            got[k] = g
+        if eps != 0.0:
+            assert got["literal"].tobytes() == got["stack"].tobytes()
+    a = svo.DeviceBuffer.from_numpy(got["stack"]); p = svo.DeviceBuffer(3 * 8); b = svo.DeviceBuffer(3 * 32)
+    svo.gbuffer_pack(a.ptr, p.ptr, 3); svo.gbuffer_unpack(p.ptr, b.ptr, 3)
+    svo.lib.svo_stream_synchronize(None)
+    assert np.array_equal(b.to_numpy(svo.HIT_DTYPE, 3)["flags"], got["stack"]["flags"]) and (got["stack"]["flags"][0] & svo.ERR_FLAG)
+
+
+def test_update_is_ordered_behind_queued_launches(svo, oracle):
+    """svo_world_update while launches of the world are queued on a non-blocking stream (the null stream's copies are not
+    ordered against such a stream): every launch issued before the update shows the old world, every launch after it the
+    new one, none a mixture (World::modify on the GL queue, src/World.cpp:268-274)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0            # hipStreamNonBlocking
+    O = oracle.OracleWorld.generate(2, 1, 1, 128, 7)
+    W = svo.World.create([O.chunk(i) for i in range(2)], 2, 1, 1, 128)
+    W.upload(0)
+    cam = svo.make_camera((120.0, 150.0, -60.0), (0.05, -0.55, 0.83), (0.0, 1.0, 0.0), 60.0, 480, 270)
+    prm_o = oracle.make_params(shadow=True)
+    before = O.trace_image(cam, params=prm_o, threads=8)
+    dt, dw = oracle.Delta(), oracle.Delta()
+    oracle.lib.orc_destroy(C.byref(O.w.chunk[0]), oracle.vec3((0, 0, 0)), oracle.vec3((128, 128, 90)), C.byref(dt), C.byref(dw))
+    after = O.trace_image(cam, params=prm_o, threads=8)
+    assert not np.array_equal(before["flags"], after["flags"])
+    prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK)
+    n = 24
+    bufs = [svo.DeviceBuffer(480 * 270 * 32) for _ in range(2 * n)]
+    for b in bufs[:n]:
+        W.trace(cam, prm, (0, 0, 480, 270), b.ptr, st.value)             # queued, not waited for
+    c = O.chunk(0)
+    W.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right),
+             realloc=bool(dt.realloc_ or dw.realloc_))
+    for b in bufs[n:]:
+        W.trace(cam, prm, (0, 0, 480, 270), b.ptr, st.value)
+    svo.lib.svo_stream_synchronize(st.value)
+    for i, b in enumerate(bufs):
+        assert_gbuffer_equal(b.to_numpy(svo.HIT_DTYPE, 480 * 270), (before if i < n else after), f"launch {i}")
+    hip.hipStreamDestroy(st)
+    W.destroy()
