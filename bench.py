@@ -383,11 +383,38 @@ def run(args):
             dt = float(et.item())
         return dt
 
-    # ---- untimed: rays of every camera of the path (primary + shadow; this rank's share, then summed over the ranks)
+    # ---- untimed preamble.  N = 1: every camera of the path is traced once by the literal kernel (its reference work
+    # counters price the algorithmic bytes; its launch also counts the frame's rays), then the path is traced group by
+    # group by the timed kernel - launches of the same shape as the timed ones - and every frame must equal the literal
+    # kernel's G-buffer.  N > 1: this rank's share of every camera is traced once and the ray counts are summed over ranks.
     rays_local = []
-    for c in path:
-        trace_group(0, [c])
-        rays_local.append(world.last_ray_count(streams[0].cuda_stream))
+    algo_cam = None
+    counters_sum = None
+    if not multi and not args.emulate_share:
+        algo_cam = []
+        counters_sum = dict(node_words=0, brick_cells=0, chunk_descs=0, tree_steps=0)
+        cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
+        tmp = torch.empty((G, ih, iw, rec), dtype=torch.uint8, device=dev)
+        cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
+        for first in range(0, P, G):
+            group = list(range(first, min(first + G, P)))
+            for f, ci in enumerate(group):
+                world.trace(path[ci], cprm, (0, 0, iw, ih), tmp[f].data_ptr(), stream)
+                rays_local.append(world.last_ray_count(stream))
+                csum = cnt.to(torch.int64).sum(dim=0).tolist()
+                for key, v in zip(list(counters_sum), csum):
+                    counters_sum[key] += v
+                algo_cam.append(4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih)
+            trace_group(0, [path[ci] for ci in group])          # the fast kernel must produce the literal kernel's G-buffers
+            torch.cuda.synchronize()
+            for f, ci in enumerate(group):
+                if not torch.equal(tmp[f], bufs[0][f]):
+                    raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
+        del tmp, cnt
+    else:
+        for c in path:
+            trace_group(0, [c])
+            rays_local.append(world.last_ray_count(streams[0].cuda_stream))
     rays_t = torch.tensor(rays_local, dtype=torch.int64, device=cdev)
     seen_t = torch.ones(1, dtype=torch.int64, device=cdev)
     if multi:
@@ -403,29 +430,6 @@ def run(args):
 
     def rays_of(steps, fixed=False):
         return steps * rays_cam[0] if fixed else sum(rays_cam[i % P] for i in range(steps))
-
-    # ---- untimed, N=1: algorithmic bytes of every camera's frame from the reference work counters, and the
-    # stack-vs-literal self-check of every distinct frame
-    algo_cam = None
-    counters_sum = None
-    if not multi and not args.emulate_share:
-        algo_cam = []
-        counters_sum = dict(node_words=0, brick_cells=0, chunk_descs=0, tree_steps=0)
-        cnt = torch.zeros((ih * iw, 4), dtype=torch.int32, device=dev)
-        tmp = torch.empty((ih, iw, rec), dtype=torch.uint8, device=dev)
-        cprm = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_LITERAL, counters_dev=cnt.data_ptr())
-        for ci, c in enumerate(path):
-            world.trace(c, cprm, (0, 0, iw, ih), tmp.data_ptr(), stream)
-            torch.cuda.synchronize()
-            csum = cnt.to(torch.int64).sum(dim=0).tolist()
-            for key, v in zip(list(counters_sum), csum):
-                counters_sum[key] += v
-            algo_cam.append(4 * csum[0] + 2 * csum[1] + 32 * csum[2] + rec * iw * ih)
-            trace_group(0, [c])                     # the fast kernel must produce the literal kernel's G-buffer
-            torch.cuda.synchronize()
-            if not torch.equal(tmp, bufs[0][0]):
-                raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
-        del tmp, cnt
 
     # ---- warmup
     works = [None] * S

@@ -22,7 +22,7 @@
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
  *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
  *   svo_world_shift      <- World::shift                           src/World.cpp:334-378
- *   svo_shade            <- lighting of fragment main               shaders/World.Fragment.glsl:63-138,180-197
+ *   svo_shade(_packed)   <- lighting of fragment main               shaders/World.Fragment.glsl:63-138,180-197
  *
  * Conventions
  *   - plain C, opaque handle, caller owns every buffer it passes in;
@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 1
+#define SVO_ABI_VERSION 2           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record */
 
 typedef enum svo_status {
     SVO_OK                 =  0,
@@ -149,13 +149,22 @@ typedef struct svo_trace_params {
     uint32_t *counters_dev;         /* optional [n][4] u32 per ray: node words, brick cells, chunk
                                        descriptors, tree steps (reference restart-from-root counts);
                                        only honoured by SVO_KERNEL_LITERAL */
+    int32_t  normal_mode;           /* SVO_NORMAL_CUBE (0): svo_hit.normal = the reference's cubeNormal, bit for bit - NaN where
+                                       its integer vector is (0,0,0): 0.1 % of the hits at depth 8, 14 % at depth 12.
+                                       SVO_NORMAL_FACE (1): the unit vector of the voxel face the sample point
+                                       alpha + beta*(t - EPS) lies closest to (axis of the largest |point - centre|, first axis
+                                       on ties; signed like that component, against the ray if it is exactly 0) - the face the
+                                       ray entered through, defined for every hit; such records carry SVO_FACE_NORMAL */
+    int32_t  _reserved;
 } svo_trace_params;
+enum { SVO_NORMAL_CUBE = 0, SVO_NORMAL_FACE = 1 };
 
 /* G-buffer record, 32 bytes per pixel / per ray. */
 enum {
     SVO_HIT_FLAG      = 1u << 0,    /* primary ray hit a voxel */
     SVO_SHADOW_TRACED = 1u << 1,    /* a shadow ray was cast from this hit */
     SVO_SHADOWED      = 1u << 2,    /* ... and it hit something */
+    SVO_FACE_NORMAL   = 1u << 3,    /* normal[] is the entered-face normal (svo_trace_params.normal_mode = SVO_NORMAL_FACE) */
     SVO_ERR_FLAG      = 1u << 15    /* runaway ray: given up after 2^22 march steps of the kernel's own counting (only rays that
                                        creep through all three nested loops of the reference get there; the stack kernel
                                        takes creeping stretches in closed form and finishes rays the literal kernel gives
@@ -297,6 +306,10 @@ void svo_shade_defaults(svo_shade_params *p);
 /* Shade the rectangle a svo_trace(cam, x0, y0, w, h) call filled: gbuffer_dev has w*h records, rgba_dev w*h float4. */
 int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
               const svo_hit *gbuffer_dev, float *rgba_dev, void *stream);
+/* The same over the 8-byte records of svo_gbuffer_pack (what rank 0 holds after the multi-GPU gather): 8 B read + 16 B
+ * written per pixel instead of 32 + 16; identical colours (the packed record carries t, normal, material, flags). */
+int svo_shade_packed(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+                     const uint64_t *packed_dev, float *rgba_dev, void *stream);
 
 /* Number of rays the last launch on this world actually marched (primary + shadow, all frames of a
  * svo_trace_frames launch; a multi-frame call served by a kernel other than SVO_KERNEL_STACK is one launch per

@@ -44,7 +44,8 @@ ERR_NAMES = {0: "SVO_OK", -1: "SVO_ERR_INVALID_ARG", -2: "SVO_ERR_NO_DEVICE", -3
              -4: "SVO_ERR_MALFORMED_TREE", -5: "SVO_ERR_NOT_UPLOADED", -6: "SVO_ERR_UNSUPPORTED", -7: "SVO_ERR_HIP"}
 EMPTY, LEAF, BRANCH, TWIG = 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_LITERAL, KERNEL_STACK = 0, 1, 2
-HIT_FLAG, SHADOW_TRACED, SHADOWED, ERR_FLAG = 1, 2, 4, 1 << 15
+HIT_FLAG, SHADOW_TRACED, SHADOWED, FACE_NORMAL, ERR_FLAG = 1, 2, 4, 8, 1 << 15
+NORMAL_CUBE, NORMAL_FACE = 0, 1
 CELL_NONE = 0xFF
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("normal", "<f4", (3,)), ("material", "<u2"), ("flags", "<u2"),
@@ -80,7 +81,8 @@ class Camera(C.Structure):
 class TraceParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_chunk_steps", C.c_int32), ("max_tree_steps", C.c_int32),
                 ("max_twig_steps", C.c_int32), ("shadow", C.c_int32), ("light_dir", C.c_float * 3),
-                ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p)]
+                ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p),
+                ("normal_mode", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class Material(C.Structure):
@@ -122,7 +124,7 @@ MAX_FRAMES = 16                     # SVO_MAX_FRAMES
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
-    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_packed", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
     "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -149,6 +151,7 @@ lib.svo_gbuffer_unpack.argtypes = [_P, _P, C.c_int64, _P]
 lib.svo_shade_defaults.argtypes = [C.POINTER(ShadeParams)]
 lib.svo_shade_defaults.restype = None
 lib.svo_shade.argtypes = [C.POINTER(Camera), C.POINTER(ShadeParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]
+lib.svo_shade_packed.argtypes = [C.POINTER(Camera), C.POINTER(ShadeParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]
 lib.svo_world_upload.argtypes = [_P, C.c_int]
 lib.svo_world_update.argtypes = [_P, C.c_int, C.POINTER(ChunkDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
 lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
@@ -251,8 +254,9 @@ def c5_scene() -> dict:
 
 
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
-                 caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0) -> TraceParams:
+                 caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0, normal_mode: int = 0) -> TraceParams:
     p = TraceParams()
+    p.normal_mode = normal_mode
     p.eps = eps
     p.max_chunk_steps, p.max_tree_steps, p.max_twig_steps = caps
     p.shadow = 1 if shadow else 0
@@ -307,6 +311,12 @@ def shade_defaults() -> ShadeParams:
 def shade(cam: Camera, params: ShadeParams, rect, gbuffer_ptr: int, rgba_ptr: int, stream: int = 0):
     x0, y0, w, h = rect
     _check(lib.svo_shade(C.byref(cam), C.byref(params), x0, y0, w, h, gbuffer_ptr, rgba_ptr, stream), "svo_shade")
+
+
+def shade_packed(cam: Camera, params: ShadeParams, rect, packed_ptr: int, rgba_ptr: int, stream: int = 0):
+    """svo_shade over the 8-byte records of gbuffer_pack."""
+    x0, y0, w, h = rect
+    _check(lib.svo_shade_packed(C.byref(cam), C.byref(params), x0, y0, w, h, packed_ptr, rgba_ptr, stream), "svo_shade_packed")
 
 
 class World:
@@ -444,12 +454,12 @@ class World:
 
     # -- convenience: World::draw / chunkmarch returning numpy -------------------------------
     def draw(self, cam: Camera, rect=None, shadow: bool = False, kernel: int = KERNEL_AUTO, counters: bool = False,
-             light_dir=(1.0, -1.0, 0.0)):
+             light_dir=(1.0, -1.0, 0.0), normal_mode: int = 0):
         """Trace a rectangle of the camera image; returns the G-buffer (HIT_DTYPE[h, w]) [+ counters]."""
         x0, y0, w, h = rect if rect is not None else (0, 0, cam.width, cam.height)
         out = DeviceBuffer(max(w * h, 1) * 32)
         cnt = DeviceBuffer(max(w * h, 1) * 16) if counters else None
-        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, counters_dev=cnt.ptr if cnt else None)
+        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode)
         self.trace(cam, prm, (x0, y0, w, h), out.ptr)
         _check(lib.svo_stream_synchronize(None), "svo_stream_synchronize")
         g = out.to_numpy(HIT_DTYPE, w * h).reshape(h, w)
@@ -461,7 +471,7 @@ class World:
         return g
 
     def chunkmarch(self, origins, dirs, shadow: bool = False, kernel: int = KERNEL_AUTO, counters: bool = False,
-                   light_dir=(1.0, -1.0, 0.0), eps: float = 0.0, caps=(0, 0, 0)):
+                   light_dir=(1.0, -1.0, 0.0), eps: float = 0.0, caps=(0, 0, 0), normal_mode: int = 0):
         """chunkmarch over a ray list (src/Traverse.cpp:127-171); returns HIT_DTYPE[n] [+ counters]."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -470,7 +480,7 @@ class World:
         out = DeviceBuffer(max(n, 1) * 32)
         cnt = DeviceBuffer(max(n, 1) * 16) if counters else None
         prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, eps=eps, caps=caps,
-                           counters_dev=cnt.ptr if cnt else None)
+                           counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode)
         self.trace_rays(od.ptr, dd.ptr, n, prm, out.ptr)
         _check(lib.svo_stream_synchronize(None), "svo_stream_synchronize")
         g = out.to_numpy(HIT_DTYPE, n)

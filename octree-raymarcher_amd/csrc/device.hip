@@ -302,6 +302,7 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;
     A.cap_twig = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : 1000;
     A.shadow = (prm && prm->shadow) ? 1 : 0;
+    A.normal_mode = (prm && prm->normal_mode == SVO_NORMAL_FACE) ? SVO_NORMAL_FACE : SVO_NORMAL_CUBE;
     float l[3] = { 1.0f, -1.0f, 0.0f };                                  // src/Main.cpp:116 (normalised below)
     if (prm && (prm->light_dir[0] != 0.0f || prm->light_dir[1] != 0.0f || prm->light_dir[2] != 0.0f))
         std::memcpy(l, prm->light_dir, sizeof l);

@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256) void k_trace_literal(TraceArgs A)
         bool runaway = false;
         if (lit_world(A, o, d, t, vox, chunk, cnt, runaway)) {
             const V3 point = o + d * (t - A.eps);
-            const V3 n = cube_normal(point, vox.lo, vox.lo + vox.size, A.eps);
-            uint32_t flags = SVO_HIT_FLAG;
+            const bool face = A.normal_mode == SVO_NORMAL_FACE;
+            const V3 n = face ? face_normal(point, vox.lo, vox.lo + vox.size, d) : cube_normal(point, vox.lo, vox.lo + vox.size, A.eps);
+            uint32_t flags = SVO_HIT_FLAG | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
             if (A.shadow) {
                 Voxel sv; float st; uint32_t sc;
                 const bool occluded = lit_world(A, point, ld3(A.sdir), st, sv, sc, cnt, runaway);

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
         if (mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD) {     // runaway ray: give up, flag it
-            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG);
+            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
             else store_miss(A.out, outk, SVO_ERR_FLAG);
             mode = M_DONE;
         }
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && outk < 0) {
-            store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED);
+            store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
             mode = M_DONE;
         }
         if (run_hit && mode == M_HIT) {
@@ -684,8 +684,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 material = A.twig[((unsigned long long)twig_off + node_offset(word)) * TWIG_WORDS + hitc];
             }
             const V3 point = alpha + beta * (tw - eps);
-            const V3 n = cube_normal_pow2(point, vlo, vsize, eps);
-            const uint32_t flags = SVO_HIT_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u);
+            const bool face = A.normal_mode == SVO_NORMAL_FACE;
+            const V3 n = face ? face_normal(point, vlo, vlo + vsize, beta) : cube_normal_pow2(point, vlo, vsize, eps);
+            const uint32_t flags = SVO_HIT_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u) | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
             store_hit(A.out, outk, tw, n, material, flags, (uint32_t)ci, node, hitc);
             mode = M_DONE;
             if (A.shadow) {                             // the lane becomes its own shadow ray

@@ -71,6 +71,21 @@ __device__ __forceinline__ V3 cube_normal(V3 s, V3 lo, V3 hi, float eps)
     return normalize3(mk((float)(int)n.x, (float)(int)n.y, (float)(int)n.z));
 }
 
+// The build's entered-face normal (svo_trace_params.normal_mode = SVO_NORMAL_FACE; not in the reference): unit vector of the
+// voxel face the sample point s lies closest to - axis of the largest |s - centre| (first axis on ties), signed like that
+// component, against the ray when it is exactly 0.  Never NaN.
+__device__ __forceinline__ V3 face_normal(V3 s, V3 lo, V3 hi, V3 beta)
+{
+    const V3 c = (lo + hi) * 0.5f;
+    const V3 p = s - c;
+    const float ax = fabsf(p.x), ay = fabsf(p.y), az = fabsf(p.z);
+    int k = 0; float pk = p.x, bk = beta.x, ak = ax;
+    if (ay > ak) { k = 1; pk = p.y; bk = beta.y; ak = ay; }
+    if (az > ak) { k = 2; pk = p.z; bk = beta.z; ak = az; }
+    const float sgn = pk > 0.0f ? 1.0f : pk < 0.0f ? -1.0f : (bk > 0.0f ? -1.0f : 1.0f);
+    return mk(k == 0 ? sgn : 0.0f, k == 1 ? sgn : 0.0f, k == 2 ? sgn : 0.0f);
+}
+
 __device__ __forceinline__ int pmod(int n, int m) { return (m + (n % m)) % m; }   // src/World.cpp:276-279
 
 // World::index(World::index_float(p)), src/World.cpp:288-293,323-332

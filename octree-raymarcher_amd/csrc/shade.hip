@@ -23,42 +23,88 @@ struct ShadeArgs {
     // per-launch constants worked out once on the host with the same float expressions the per-pixel code used:
     float gdiffuse[8][3], gspecular[8][3];      // pow(material.diffuse / .specular, gamma), :183-184
     float dir_l[3], spot_axis[3];               // normalize(-directional.direction), normalize(-spot.direction)
+    float inv_imgw, inv_imgh, inv_spot_delta, inv_near, inv_depth_range;    // 1/width, 1/height, 1/(cos_phi - cos_gamma), 1/near, 1/(1/far - 1/near)
 };
 
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float length3(V3 v) { return sqrtf(dot3(v, v)); }
+// The shading stage is compared with the oracle to 2e-5 relative (tests/test_shading.py), not bit for bit (powf already
+// differs between glibc and the device), so reciprocals and inverse square roots are the hardware's 1-ulp instructions
+// instead of IEEE division sequences: ~20 VALU less per normalisation, seven normalisations per pixel.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ V3 normalize_fast(V3 v) { return v * __builtin_amdgcn_rsqf(dot3(v, v)); }
 __device__ __forceinline__ float maxf0(float x) { return (x < 0.0f) ? 0.0f : x; }          // max(x, 0.0)
-__device__ __forceinline__ float attenuation(float kc, float kl, float kq, float d) { return 1.0f / (kc + kl * d + kq * d * d); }   // :75-78
+__device__ __forceinline__ float attenuation(float kc, float kl, float kq, float d) { return rcp_fast(kc + kl * d + kq * d * d); }   // :75-78
+// pow(x, y) for x in [0, 1], y >= 0 as exp2(y * log2(x)).  The exponent y * log2(x) must be good to ~1e-5 absolute
+// wherever the result is not negligible, i.e. for |y * log2(x)| < 20: near x = 1 (the only place a shininess of 10000
+// leaves anything) log2(x) comes from the series of ln(1 - d), d = 1 - x exact, relative error ~1e-7; elsewhere from the
+// hardware's 1-ulp log2, whose absolute error (~1e-7) times y stays below 1e-5 for y <= 100 and is irrelevant above
+// (the result underflows).  No library powf: three of them were a third of the kernel.
+__device__ __forceinline__ float pow_shiny(float x, float y)
+{
+    if (y == 0.0f) return 1.0f;                                     // pow(x, 0) = 1, also for x = 0
+    if (!(x > 0.0f)) return 0.0f;
+    const float d = 1.0f - x;
+    const float series = -(d + d * d * (0.5f + d * (0.33333334f + d * 0.25f))) * 1.44269504f;       // log2(1 - d), d < 1/64
+    const float l2 = d < 0.015625f ? series : __builtin_amdgcn_logf(x);
+    return __builtin_amdgcn_exp2f(y * l2);
+}
+// normalize(ivec3 in {-1,0,1}^3) from the packed record's 2-bit-per-axis code (bit 6: NaN), as k_gbuffer_unpack
+__device__ __forceinline__ V3 normal_from_code(uint32_t code)
+{
+    if (code & (1u << 6)) { const float q = __uint_as_float(0x7FC00000u); return mk(q, q, q); }
+    const float ix = (float)((int)(code & 3u) - 1), iy = (float)((int)((code >> 2) & 3u) - 1), iz = (float)((int)((code >> 4) & 3u) - 1);
+    const float dot = ix * ix + iy * iy + iz * iz;
+    const float inv = dot == 1.0f ? 1.0f : dot == 2.0f ? __uint_as_float(0x3F3504F3u) : dot == 3.0f ? __uint_as_float(0x3F13CD3Au) : __uint_as_float(0x7FC00000u);
+    return mk(ix * inv, iy * inv, iz * inv);
+}
 
+// PACKED: the G-buffer is the 8-byte form of svo_gbuffer_pack (8 B read + 16 B written per pixel instead of 32 + 16)
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= (int64_t)A.w * A.h) return;
-    const uint4 r0 = A.gbuffer[2 * k], r1 = A.gbuffer[2 * k + 1];
-    const uint32_t flags = r1.x >> 16, material = r1.x & 0xFFFFu;
+    uint32_t flags, material;
+    float t;
+    V3 n;
+    if (PACKED) {
+        const uint2 r = reinterpret_cast<const uint2 *>(A.gbuffer)[k];
+        t = __uint_as_float(r.x); material = r.y & 0xFFFFu; flags = (r.y >> 16) & 0xFFu;
+        n = normal_from_code((r.y >> 24) & 0x7Fu);
+    } else {
+        const uint4 r0 = A.gbuffer[2 * k], r1 = A.gbuffer[2 * k + 1];
+        flags = r1.x >> 16; material = r1.x & 0xFFFFu;
+        t = __uint_as_float(r0.x);
+        n = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+    }
     if (!(flags & SVO_HIT_FLAG)) { A.rgba[k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }       // discard
     const svo_shade_params &P = A.P;
     // the ray of this pixel (same generation as the march) and the shaded point alpha + beta * (sigma - EPS), :174
     const int px = A.x0 + (int)(k % A.w), py = A.y0 + (int)(k / A.w);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const float u = ((fx / (float)A.imgw) * 2.0f - 1.0f) * A.tanx;
-    const float v = (1.0f - (fy / (float)A.imgh) * 2.0f) * A.tany;
+    const float u = ((fx * A.inv_imgw) * 2.0f - 1.0f) * A.tanx;
+    const float v = (1.0f - (fy * A.inv_imgh) * 2.0f) * A.tany;
     const V3 eye = ld3(A.eye);
-    const V3 beta = normalize3((ld3(A.fwd) + ld3(A.right) * u) + ld3(A.up) * v);
-    const float t = __uint_as_float(r0.x);
-    const V3 p = eye + beta * (t - P.eps);
-    const V3 n = mk(__uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
-    const svo_material &M = P.materials[material < 8 ? material : 0];
-    const V3 diffuse = ld3(A.gdiffuse[material < 8 ? material : 0]), specular = ld3(A.gspecular[material < 8 ? material : 0]);     // :183-184
+    const V3 beta = normalize_fast((ld3(A.fwd) + ld3(A.right) * u) + ld3(A.up) * v);
+    const float sdist = t - P.eps;
+    const V3 p = eye + beta * sdist;
+    const int mi = material < 8 ? (int)material : 0;
+    const float shininess = P.materials[mi].shininess;
+    const V3 diffuse = ld3(A.gdiffuse[mi]), specular = ld3(A.gspecular[mi]);                          // :183-184
     const float lit = (flags & SVO_SHADOWED) ? 0.0f : 1.0f;                                          // (1.0 - shadow)
-    const V3 vdir = normalize3(eye - p);
+    // normalize(eye - p) = -beta and |p - eye| = sigma - EPS (beta is a unit vector) while the hit lies in front of the eye
+    const bool front = sdist > 1.0e-3f;
+    const V3 vdir = front ? mk(-beta.x, -beta.y, -beta.z) : normalize_fast(eye - p);
+    const float zdist = front ? sdist : sqrtf(dot3(p - eye, p - eye));
     V3 color = mk(0.0f, 0.0f, 0.0f);
     {   // computePointLight_BlinnPhong, :80-97
-        const V3 l = normalize3(ld3(P.point.position) - p);
-        const V3 hv = normalize3(l + vdir);
+        const V3 lv = ld3(P.point.position) - p;
+        const float l2 = dot3(lv, lv), il = __builtin_amdgcn_rsqf(l2);
+        const V3 l = lv * il;
+        const V3 hv = normalize_fast(l + vdir);
         const float d = maxf0(dot3(n, l));
-        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
-        const float att = attenuation(P.point.constant, P.point.linear, P.point.quadratic, length3(p - ld3(P.point.position)));
+        const float s = pow_shiny(maxf0(dot3(vdir, hv)), shininess);
+        const float att = attenuation(P.point.constant, P.point.linear, P.point.quadratic, l2 * il);     // |p - position| = l2 / sqrt(l2)
         const V3 amb = ld3(P.point.ambient) * diffuse;
         const V3 dif = ((ld3(P.point.diffuse) * d) * diffuse) * lit;
         const V3 spe = ((ld3(P.point.specular) * s) * specular) * lit;
@@ -66,23 +112,24 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
     }
     {   // computeDirectionalLight_BlinnPhong, :99-114
         const V3 l = ld3(A.dir_l);
-        const V3 hv = normalize3(l + vdir);
+        const V3 hv = normalize_fast(l + vdir);
         const float d = maxf0(dot3(n, l));
-        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
+        const float s = pow_shiny(maxf0(dot3(vdir, hv)), shininess);
         const V3 amb = ld3(P.directional.ambient) * diffuse;
         const V3 dif = ((ld3(P.directional.diffuse) * d) * diffuse) * lit;
         const V3 spe = ((ld3(P.directional.specular) * s) * specular) * lit;
         color = color + ((amb + dif) + spe);
     }
     {   // computeSpotlight_BlinnPhong, :116-138
-        const V3 l = normalize3(ld3(P.spot.position) - p);
-        const V3 hv = normalize3(l + vdir);
+        const V3 lv = ld3(P.spot.position) - p;
+        const float l2 = dot3(lv, lv), il = __builtin_amdgcn_rsqf(l2);
+        const V3 l = lv * il;
+        const V3 hv = normalize_fast(l + vdir);
         const float d = maxf0(dot3(n, l));
-        const float s = powf(maxf0(dot3(vdir, hv)), M.shininess);
-        const float att = attenuation(P.spot.constant, P.spot.linear, P.spot.quadratic, length3(p - ld3(P.spot.position)));
+        const float s = pow_shiny(maxf0(dot3(vdir, hv)), shininess);
+        const float att = attenuation(P.spot.constant, P.spot.linear, P.spot.quadratic, l2 * il);
         const float theta = dot3(l, ld3(A.spot_axis));
-        const float delta = P.spot.cos_phi - P.spot.cos_gamma;
-        float intensity = (theta - P.spot.cos_gamma) / delta;
+        float intensity = (theta - P.spot.cos_gamma) * A.inv_spot_delta;
         intensity = (intensity < 0.0f) ? 0.0f : intensity;                      // clamp = min(max(x, 0), 1)
         intensity = (1.0f < intensity) ? 1.0f : intensity;
         const V3 amb = ld3(P.spot.ambient) * diffuse;
@@ -90,8 +137,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs A)
         const V3 spe = ((ld3(P.spot.specular) * s) * specular) * lit;
         color = color + (amb + (dif + spe) * intensity) * att;
     }
-    const float inv_z = 1.0f / length3(p - eye), inv_near = 1.0f / P.near_plane, inv_far = 1.0f / P.far_plane;     // :193-197
-    A.rgba[k] = make_float4(color.x, color.y, color.z, (inv_z - inv_near) / (inv_far - inv_near));
+    A.rgba[k] = make_float4(color.x, color.y, color.z, (rcp_fast(zdist) - A.inv_near) * A.inv_depth_range);     // :193-197
 }
 
 // ---- packed G-buffer -------------------------------------------------------------------------------------------
@@ -189,8 +235,8 @@ static int pack_common(const void *in, void *out, int64_t n, void *stream, bool 
 int svo_gbuffer_pack(const svo_hit *gbuffer_dev, uint64_t *packed_dev, int64_t n, void *stream) { return pack_common(gbuffer_dev, packed_dev, n, stream, true); }
 int svo_gbuffer_unpack(const uint64_t *packed_dev, svo_hit *gbuffer_dev, int64_t n, void *stream) { return pack_common(packed_dev, gbuffer_dev, n, stream, false); }
 
-int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
-              const svo_hit *gbuffer_dev, float *rgba_dev, void *stream)
+static int shade_impl(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+                      const void *gbuffer_dev, float *rgba_dev, void *stream, bool packed)
 {
     if (!cam || !p || !gbuffer_dev || !rgba_dev || w < 0 || h < 0 || x0 < 0 || y0 < 0 || cam->width <= 0 || cam->height <= 0) {
         set_error("svo_shade: bad argument"); return SVO_ERR_INVALID_ARG;
@@ -216,14 +262,31 @@ int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, 
     };
     unit_neg(A.P.directional.direction, A.dir_l);
     unit_neg(A.P.spot.direction, A.spot_axis);
+    A.inv_imgw = 1.0f / (float)cam->width; A.inv_imgh = 1.0f / (float)cam->height;
+    A.inv_spot_delta = 1.0f / (A.P.spot.cos_phi - A.P.spot.cos_gamma);
+    A.inv_near = 1.0f / A.P.near_plane;
+    A.inv_depth_range = 1.0f / (1.0f / A.P.far_plane - 1.0f / A.P.near_plane);
     A.gbuffer = reinterpret_cast<const uint4 *>(gbuffer_dev);
     A.rgba = reinterpret_cast<float4 *>(rgba_dev);
     const int64_t n = (int64_t)w * h;
     if (n == 0) return SVO_OK;
-    hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    if (packed) hipLaunchKernelGGL(k_shade<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_shade<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("svo_shade: ") + hipGetErrorString(e)); return e == hipErrorNoDevice ? SVO_ERR_NO_DEVICE : SVO_ERR_HIP; }
     return SVO_OK;
+}
+
+int svo_shade(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+              const svo_hit *gbuffer_dev, float *rgba_dev, void *stream)
+{
+    return shade_impl(cam, p, x0, y0, w, h, gbuffer_dev, rgba_dev, stream, false);
+}
+
+int svo_shade_packed(const svo_camera *cam, const svo_shade_params *p, int x0, int y0, int w, int h,
+                     const uint64_t *packed_dev, float *rgba_dev, void *stream)
+{
+    return shade_impl(cam, p, x0, y0, w, h, packed_dev, rgba_dev, stream, true);
 }
 
 } // extern "C"

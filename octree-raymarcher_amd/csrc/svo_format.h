@@ -71,6 +71,7 @@ struct TraceArgs {
     float    eps;
     int32_t  cap_chunk, cap_tree, cap_twig;
     int32_t  shadow;
+    int32_t  normal_mode;       // SVO_NORMAL_CUBE / SVO_NORMAL_FACE
     float    sdir[3];           // normalize(-light_dir), computed on the host
     // outputs
     void     *out;              // svo_hit[n]

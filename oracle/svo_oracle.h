@@ -81,6 +81,7 @@ typedef struct orc_params {
     int32_t max_chunk_steps, max_tree_steps, max_twig_steps;   /* 0 -> 1000 */
     int32_t shadow;
     float   light_dir[3];
+    int32_t normal_mode;          /* 0: cubeNormal (shaders/Chunkmarch.glsl:128-136); 1: the build's entered-face normal (never NaN) */
 } orc_params;
 
 typedef struct orc_camera {       /* identical to svo_camera */

@@ -12,6 +12,7 @@ P = svo.shade_defaults()
 for _ in range(20):
     svo.shade(cam, P, (0, 0, w, h), g.ptr, rgba.ptr)
     svo.gbuffer_pack(g.ptr, p.ptr, w * h)
+    svo.shade_packed(cam, P, (0, 0, w, h), p.ptr, rgba.ptr)
     svo.gbuffer_unpack(p.ptr, g2.ptr, w * h)
 svo.lib.svo_stream_synchronize(None)
 print("bricks", W.info.total_twigs)

@@ -473,3 +473,35 @@ def test_update_is_ordered_behind_queued_launches(svo, oracle):
         assert_gbuffer_equal(b.to_numpy(svo.HIT_DTYPE, 480 * 270), (before if i < n else after), f"launch {i}")
     hip.hipStreamDestroy(st)
     W.destroy()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_face_normal_mode(svo, oracle, worlds, kernel):
+    """svo_trace_params.normal_mode = SVO_NORMAL_FACE: the entered-face normal (an axis unit vector, never NaN), flagged
+    SVO_FACE_NORMAL, equal to the oracle's restatement and to the reference's cubeNormal wherever that one names a face;
+    it survives the packed record; mode 0 stays the reference's formula, NaNs and all."""
+    W, O, lo, hi, _ = worlds["depth10"]
+    cam = svo.default_camera(1, 1, 128, 480, 270)
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True, normal_mode=1), threads=8)
+    got = W.draw(cam, shadow=True, kernel=_kid(svo, kernel), normal_mode=svo.NORMAL_FACE)
+    assert_gbuffer_equal(got, want, f"face normal/{kernel}")
+    hit = (got["flags"] & svo.HIT_FLAG) != 0
+    assert hit.sum() > 20000 and np.all((got["flags"][hit] & svo.FACE_NORMAL) != 0) and not np.any(got["flags"][~hit] & svo.FACE_NORMAL)
+    n = got["normal"][hit]
+    assert not np.isnan(n).any()
+    assert np.all(np.abs(n).sum(axis=1) == 1.0) and np.all((np.abs(n) == 1.0).sum(axis=1) == 1)       # +-1 on exactly one axis
+    ref = W.draw(cam, shadow=True, kernel=_kid(svo, kernel))                                           # mode 0: cubeNormal
+    assert not np.any(ref["flags"] & svo.FACE_NORMAL)
+    for f in ("t", "material", "chunk", "node", "cell"):
+        assert np.array_equal(ref[f], got[f])                                                          # only normal and the flag differ
+    rn = ref["normal"][hit]
+    face = (~np.isnan(rn).any(axis=1)) & ((np.abs(rn) == 1.0).sum(axis=1) == 1)                        # cubeNormal found one face
+    assert np.isnan(rn).any() and face.mean() > 0.5
+    assert np.array_equal(rn[face], n[face])
+    # packed record round trip
+    flat = got.reshape(-1)
+    a = svo.DeviceBuffer.from_numpy(flat); p = svo.DeviceBuffer(flat.size * 8); b = svo.DeviceBuffer(flat.size * 32)
+    svo.gbuffer_pack(a.ptr, p.ptr, flat.size); svo.gbuffer_unpack(p.ptr, b.ptr, flat.size)
+    svo.lib.svo_stream_synchronize(None)
+    back = b.to_numpy(svo.HIT_DTYPE, flat.size)
+    assert np.array_equal(back["flags"], flat["flags"]) and np.array_equal(back["normal"][hit.reshape(-1)], n)
