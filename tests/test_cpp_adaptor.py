@@ -28,3 +28,36 @@ def test_adaptor_draw_and_chunkmarch_on_gpu():
     r = subprocess.run([EXE, "6"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "cursor hit" in r.stdout
+
+
+MULTI = os.path.join(HOST, "multi_gpu_example")
+
+
+def build_multi():
+    """The C++ multi-GPU host (multi_gpu.hpp: N devices in one process, svo_trace_rows + svo_gbuffer_pack per device,
+    grouped ncclSend / ncclRecv of the bands into their rows of the frame on device 0) links against librccl."""
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I.", "multi_gpu_example.cpp", "-L..", "-lsvo_amd",
+                    "-lrccl", "-Wl,-rpath,$ORIGIN/..", "-o", "multi_gpu_example"], cwd=HOST, check=True)
+
+
+def test_multi_gpu_host_compiles_links_rccl_and_refuses_missing_devices(svo):
+    build_multi()
+    r = subprocess.run([MULTI, "64"], capture_output=True, text=True)          # no node has 64 devices
+    assert r.returncode == 3 and "devices asked for" in r.stderr
+    ldd = subprocess.run(["ldd", MULTI], capture_output=True, text=True).stdout
+    assert "librccl" in ldd and "libsvo_amd" in ldd
+
+
+@pytest.mark.gpu
+def test_multi_gpu_host_frame_equals_single_device_frame():
+    """With every device present on the box (1 here; the driver's 8-GPU node runs the same binary with 8): the gathered,
+    de-interleaved packed frame equals the frame device 0 traces alone, record for record."""
+    import ctypes
+    build_multi()
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    n = ctypes.c_int()
+    assert hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value >= 1
+    for ndev in sorted({1, min(2, n.value), n.value}):
+        r = subprocess.run([MULTI, str(ndev), "8"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "0 records differ" in r.stdout
