@@ -297,7 +297,10 @@ struct DeviceGrower {
     DevBuf<uint16_t> twig;
     DevBuf<unsigned char> scan_tmp;
 
-    int grow(ChunkPools &c, const float position[3], float size, uint32_t depth, const DevPyramid &P, const TerrainParams &tp, hipStream_t s)
+    // The node words go to the host copy (the water fill edits them there); the bricks stay in HBM: *bricks_dev receives the
+    // device array (caller owns it, hipFree), c.twigs_on_device their number.
+    int grow(ChunkPools &c, const float position[3], float size, uint32_t depth, const DevPyramid &P, const TerrainParams &tp, hipStream_t s,
+             uint16_t **bricks_dev)
     {
         c.position[0] = position[0]; c.position[1] = position[1]; c.position[2] = position[2];
         c.size = size; c.depth = depth;
@@ -349,55 +352,79 @@ struct DeviceGrower {
             edge = half;
         }
         c.tree.resize(trees);
-        c.twig.resize(twigs * TWIG_WORDS);
+        c.twig.clear();
         BUILD_TRY(hipMemcpyAsync(c.tree.data(), tree.p, trees * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (twigs) BUILD_TRY(hipMemcpyAsync(c.twig.data(), twig.p, twigs * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
         BUILD_TRY(hipStreamSynchronize(s));
+        c.twigs_on_device = twigs;
+        *bricks_dev = twig.p;                       // hand the brick array over; the next chunk gets a fresh one
+        twig.p = nullptr; twig.cap = 0;
         return SVO_OK;
     }
 };
 
 static int positive_mod_b(int n, int m) { return (m + (n % m)) % m; }
 
-// World::init on the device: same result as generate_world() in terrain.cpp.
-static int generate_world_device_impl(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
-                                      std::vector<ChunkPools> &chunks);
-
-int generate_world_device(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
-                          std::vector<ChunkPools> &chunks)
+// Ocroot::build on bricks that live in the pool (fill_box_plan recorded which): cell empty and its voxel box touches the
+// region -> material (src/Octree.cpp:395-410; cubesIntersect on closed boxes, the host Filler's expressions).
+struct DevBrickOp { uint64_t brick; float x, y, z, voxel; };
+static_assert(sizeof(DevBrickOp) == sizeof(BrickOp), "BrickOp is uploaded as it is");
+__global__ __launch_bounds__(256) void k_brick_fill(uint16_t *twig, const DevBrickOp *ops, uint32_t n, uint64_t first_brick,
+                                                    float rlx, float rly, float rlz, float rhx, float rhy, float rhz, uint32_t material)
 {
-    try { return generate_world_device_impl(device, w, h, d, chunksize, ccm, tp, chunks); }
-    catch (const std::bad_alloc &) { set_error("svo_world_generate (device builder): out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 64u) return;
+    const DevBrickOp op = ops[i >> 6];
+    const uint32_t cell = i & 63u, cx = cell & 3u, cy = (cell >> 2) & 3u, cz = cell >> 4;
+    uint16_t *p = twig + (first_brick + op.brick) * TWIG_WORDS + cell;
+    if (*p != 0) return;
+    const float lx = op.x + (float)cx * op.voxel, ly = op.y + (float)cy * op.voxel, lz = op.z + (float)cz * op.voxel;
+    const float hx = lx + op.voxel, hy = ly + op.voxel, hz = lz + op.voxel;
+    const bool touch = hx >= rlx && hy >= rly && hz >= rlz && rhx >= lx && rhy >= ly && rhz >= lz;
+    if (touch) *p = (uint16_t)material;
 }
 
-static int generate_world_device_impl(int device, int w, int h, int d, int chunksize, const int ccm[3], const TerrainParams &tp,
-                                      std::vector<ChunkPools> &chunks)
+// World::init on the device, pools left in HBM: noise, mips and grow() as kernels (above); the node words visit the host
+// for the water fill (Ocroot::build appends depth-first: order-dependent, 25 MB per depth-12 chunk), the bricks - 10x the
+// bytes - never leave the device: the fill's brick edits are applied in place by k_brick_fill.  The pools are packed
+// exactly as svo_world_upload packs them; the world is uploaded to `device` when this returns.
+static int generate_world_resident_impl(svo_world &w, int device)
 {
+    const TerrainParams &tp = w.terrain;
+    const int gw = w.width, gh = w.height, gd = w.depth, chunksize = w.chunksize;
+    const int *ccm = w.chunkcoordmin;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("svo_world_generate: no HIP device for the device builder"); return SVO_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { set_error("svo_world_generate: build_device out of range"); return SVO_ERR_INVALID_ARG; }
     BUILD_TRY(hipSetDevice(device));
-    chunks.assign((size_t)w * h * d, ChunkPools());
+    std::vector<ChunkPools> &chunks = w.chunks;
+    chunks.assign((size_t)gw * gh * gd, ChunkPools());
+    std::vector<uint16_t *> bricks(chunks.size(), nullptr);             // per chunk: its bricks as grow() left them in HBM
+    std::vector<uint64_t> grown(chunks.size(), 0);
+    std::vector<std::vector<BrickOp>> ops(chunks.size());
+    struct Cleanup { std::vector<uint16_t *> &b; ~Cleanup() { for (uint16_t *p : b) if (p) (void)hipFree(p); } } cleanup{ bricks };
     const uint32_t res = tp.pyramid_resolution ? tp.pyramid_resolution : (1u << tp.depth);
-    DevicePyramidBuilder pyr;
-    DeviceGrower grower;
     hipStream_t s = nullptr;
-    for (int zi = 0; zi < d; ++zi)
-        for (int xi = 0; xi < w; ++xi) {
-            const int cx = ccm[0] + xi, cz = ccm[2] + zi;
-            int rc = pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift,
-                               (float)cz * (float)res + (float)tp.seed, s);
-            if (rc != SVO_OK) return rc;
-            for (int yi = 0; yi < h; ++yi) {
-                const int cy = ccm[1] + yi;
-                const int idx = positive_mod_b(cy, h) * w * d + positive_mod_b(cz, d) * w + positive_mod_b(cx, w);
-                ChunkPools &c = chunks[(size_t)idx];
-                const float pos[3] = { (float)cx * (float)chunksize, (float)cy * (float)chunksize, (float)cz * (float)chunksize };
-                rc = grower.grow(c, pos, (float)chunksize, tp.depth, pyr.view, tp, s);
+    {
+        DevicePyramidBuilder pyr;
+        DeviceGrower grower;
+        for (int zi = 0; zi < gd; ++zi)
+            for (int xi = 0; xi < gw; ++xi) {
+                const int cx = ccm[0] + xi, cz = ccm[2] + zi;
+                int rc = pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift,
+                                   (float)cz * (float)res + (float)tp.seed, s);
                 if (rc != SVO_OK) return rc;
+                for (int yi = 0; yi < gh; ++yi) {
+                    const int cy = ccm[1] + yi;
+                    const int idx = positive_mod_b(cy, gh) * gw * gd + positive_mod_b(cz, gd) * gw + positive_mod_b(cx, gw);
+                    ChunkPools &c = chunks[(size_t)idx];
+                    const float pos[3] = { (float)cx * (float)chunksize, (float)cy * (float)chunksize, (float)cz * (float)chunksize };
+                    rc = grower.grow(c, pos, (float)chunksize, tp.depth, pyr.view, tp, s, &bricks[(size_t)idx]);
+                    if (rc != SVO_OK) return rc;
+                    grown[(size_t)idx] = c.twigs_on_device;
+                }
             }
-        }
-    if (tp.water) {     // Ocroot::build is order-dependent (depth-first appends): host, all chunks in parallel
+    }
+    if (tp.water) {     // Ocroot::build on the node words (host threads, all chunks in parallel); brick edits are recorded
         int nthreads = tp.threads > 0 ? tp.threads : (int)std::thread::hardware_concurrency();
         nthreads = std::max(1, std::min<int>(nthreads, (int)chunks.size()));
         std::atomic<size_t> cursor{ 0 };
@@ -409,8 +436,7 @@ static int generate_world_device_impl(int device, int w, int h, int d, int chunk
                     if (i >= chunks.size()) break;
                     ChunkPools &c = chunks[i];
                     const float hi[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
-                    DirtyRange a, b;
-                    fill_box(c, c.position, hi, (uint16_t)tp.water_material, a, b);
+                    fill_box_plan(c, c.position, hi, (uint16_t)tp.water_material, ops[i]);
                 }
             } catch (...) {
                 failed.store(1);
@@ -423,7 +449,46 @@ static int generate_world_device_impl(int device, int w, int h, int d, int chunk
         for (auto &t : pool) t.join();
         if (failed.load()) { set_error("svo_world_generate: out of host memory in the water fill"); return SVO_ERR_OUT_OF_MEMORY; }
     }
+    // pack: the layout of svo_world_upload
+    int rc = plan_pools(w);
+    if (rc != SVO_OK) return rc;
+    if ((rc = alloc_pools(w, device)) != SVO_OK) return rc;
+    DevBuf<DevBrickOp> d_ops;
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        ChunkPools &c = chunks[i];
+        const DevChunk &e = w.table[i];
+        BUILD_TRY(hipMemcpyAsync(w.d_tree + e.tree_off, c.tree.data(), c.tree.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        const uint64_t before = grown[i], now = c.twig_count();
+        uint16_t *slot = w.d_twig + e.twig_off * TWIG_WORDS;
+        if (before) BUILD_TRY(hipMemcpyAsync(slot, bricks[i], before * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        if (now > before) BUILD_TRY(hipMemsetAsync(slot + before * TWIG_WORDS, 0, (now - before) * TWIG_WORDS * sizeof(uint16_t), s));
+        if (!ops[i].empty()) {
+            if ((rc = d_ops.reserve(ops[i].size(), false, s)) != SVO_OK) return rc;
+            BUILD_TRY(hipMemcpyAsync(d_ops.p, ops[i].data(), ops[i].size() * sizeof(BrickOp), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_brick_fill, dim3(blocks_for((uint64_t)ops[i].size() * 64, 256)), dim3(256), 0, s, w.d_twig,
+                               d_ops.p, (uint32_t)ops[i].size(), (uint64_t)e.twig_off,
+                               c.position[0], c.position[1], c.position[2], c.position[0] + c.size, tp.water_level, c.position[2] + c.size,
+                               (uint32_t)tp.water_material);
+            BUILD_TRY(hipGetLastError());
+            BUILD_TRY(hipStreamSynchronize(s));             // d_ops and ops[i] are reused / freed
+        }
+        if ((rc = launch_brick_masks(w, e.twig_off, now, s)) != SVO_OK) return rc;
+        BUILD_TRY(hipStreamSynchronize(s));
+        (void)hipFree(bricks[i]); bricks[i] = nullptr;
+    }
+    BUILD_TRY(hipMemcpy(w.d_chunks, w.table.data(), chunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice));
+    BUILD_TRY(hipDeviceSynchronize());
     return SVO_OK;
+}
+
+int generate_world_resident(svo_world &w, int device)
+{
+    try {
+        const int rc = generate_world_resident_impl(w, device);
+        if (rc != SVO_OK) release_device(w);
+        return rc;
+    }
+    catch (const std::bad_alloc &) { release_device(w); set_error("svo_world_generate (device builder): out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
 }
 
 } // namespace svo

@@ -128,54 +128,105 @@ int svo_memcpy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy
 int svo_memcpy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SVO_OK; }
 int svo_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SVO_OK; }
 
-static int world_upload_impl(svo_world *w, int device)
+} // extern "C"
+
+namespace svo {
+
+int launch_brick_masks(svo_world &w, uint64_t first, uint64_t count, void *stream) { return launch_masks(w, first, count, (hipStream_t)stream); }
+
+// slots: capacity-sized like the reference (src/Allocator.cpp:30-33), 8-node / 1-brick granular, plus tail slack so that a
+// chunk that outgrows its slot can be re-packed without a full re-upload
+int plan_pools(svo_world &w)
+{
+    for (const ChunkPools &c : w.chunks)
+        if (c.size != (float)w.chunksize) { set_error("svo_world_upload: every chunk's size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
+    const size_t n = w.chunks.size();
+    w.table.assign(n, DevChunk());
+    w.tree_slot.assign(n, 0); w.twig_slot.assign(n, 0);
+    uint64_t tcur = 0, bcur = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ChunkPools &c = w.chunks[i];
+        const uint64_t tcap = std::max<uint64_t>(c.tree_capacity, c.tree.size());
+        const uint64_t bcap = std::max<uint64_t>(c.twig_capacity, c.twig_count());
+        const uint64_t base = ((tcur + 8) & ~(uint64_t)7) - 1;          // base % 8 == 7, base >= tcur
+        DevChunk &e = w.table[i];
+        e.bmin[0] = c.position[0]; e.bmin[1] = c.position[1]; e.bmin[2] = c.position[2];
+        e.levels = c.depth - TWIG_LEVELS;
+        e.tree_off = base;
+        e.twig_off = bcur;
+        w.tree_slot[i] = tcap; w.twig_slot[i] = bcap;
+        tcur = base + tcap;
+        bcur += bcap;
+    }
+    w.tree_pool_len = tcur; w.twig_pool_len = bcur;
+    w.tree_pool_cap = tcur + tcur / 4 + 64;
+    w.twig_pool_cap = bcur + bcur / 4 + 16;
+    return SVO_OK;
+}
+
+int alloc_pools(svo_world &w, int device)
+{
+    if (hipSetDevice(device) != hipSuccess) { set_error("svo_world_upload: hipSetDevice failed"); return SVO_ERR_NO_DEVICE; }
+    w.device = device;
+    const size_t n = w.chunks.size();
+    if (hipMalloc((void **)&w.d_tree, w.tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_twig, w.twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_mask, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
+        hipMalloc((void **)&w.d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+        set_error("svo_world_upload: hipMalloc failed"); return SVO_ERR_OUT_OF_MEMORY;
+    }
+    if (hipMemset(w.d_tree, 0, w.tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(w.d_mask, 0, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(w.d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); return SVO_ERR_HIP; }
+    w.occupancy_blocks = 0;
+    return SVO_OK;
+}
+
+// A chunk built on the device keeps its bricks there until somebody asks for the host copy.
+int fetch_bricks(svo_world &w, int chunk)
+{
+    ChunkPools &c = w.chunks[(size_t)chunk];
+    if (!c.twigs_on_device) return SVO_OK;
+    if (w.device < 0 || !w.d_twig) { set_error("fetch_bricks: the device copy is gone"); return SVO_ERR_NOT_UPLOADED; }
+    HIP_TRY(hipSetDevice(w.device));
+    const uint64_t n = c.twigs_on_device;
+    c.twig.resize(n * TWIG_WORDS);
+    HIP_TRY(hipMemcpy(c.twig.data(), w.d_twig + w.table[(size_t)chunk].twig_off * TWIG_WORDS, n * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    c.twigs_on_device = 0;
+    return SVO_OK;
+}
+
+} // namespace svo
+
+extern "C" {
+
+static int world_upload_impl(svo_world *w, int device, bool force = false)
 {
     if (!w) return SVO_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("svo_world_upload: no HIP device"); return SVO_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { set_error("svo_world_upload: device index out of range"); return SVO_ERR_INVALID_ARG; }
-    for (const ChunkPools &c : w->chunks)
-        if (c.size != (float)w->chunksize) { set_error("svo_world_upload: every chunk's size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
-    release_device(*w);
-    HIP_TRY(hipSetDevice(device));
-    w->device = device;
-
-    // slots: capacity-sized like the reference, 8-node / 1-brick granular
-    const size_t n = w->chunks.size();
-    w->table.assign(n, DevChunk());
-    w->tree_slot.assign(n, 0); w->twig_slot.assign(n, 0);
-    uint64_t tcur = 0, bcur = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const ChunkPools &c = w->chunks[i];
-        const uint64_t tcap = std::max<uint64_t>(c.tree_capacity, c.tree.size());
-        const uint64_t bcap = std::max<uint64_t>(c.twig_capacity, c.twig_count());
-        const uint64_t base = ((tcur + 8) & ~(uint64_t)7) - 1;          // base % 8 == 7, base >= tcur
-        DevChunk &e = w->table[i];
-        e.bmin[0] = c.position[0]; e.bmin[1] = c.position[1]; e.bmin[2] = c.position[2];
-        e.levels = c.depth - TWIG_LEVELS;
-        e.tree_off = base;
-        e.twig_off = bcur;
-        w->tree_slot[i] = tcap; w->twig_slot[i] = bcap;
-        tcur = base + tcap;
-        bcur += bcap;
+    // a world generated on this device is already resident there, pools packed exactly as below
+    bool resident_only = false;
+    for (const ChunkPools &c : w->chunks) resident_only |= c.twigs_on_device != 0;
+    if (resident_only && w->device == device && !force) return SVO_OK;
+    for (size_t i = 0; i < w->chunks.size(); ++i) {                     // moving elsewhere: the host copy must be complete first
+        const int rc = fetch_bricks(*w, (int)i);
+        if (rc != SVO_OK) return rc;
     }
-    // tail slack so that a chunk that outgrows its slot can be re-packed without a full re-upload
-    w->tree_pool_len = tcur; w->twig_pool_len = bcur;
-    w->tree_pool_cap = tcur + tcur / 4 + 64;
-    w->twig_pool_cap = bcur + bcur / 4 + 16;
+    int rc = plan_pools(*w);
+    if (rc != SVO_OK) return rc;
+    const std::vector<DevChunk> table = w->table;
+    const std::vector<uint64_t> tslot = w->tree_slot, bslot = w->twig_slot;
+    const uint64_t tl = w->tree_pool_len, bl = w->twig_pool_len, tc = w->tree_pool_cap, bc = w->twig_pool_cap;
+    release_device(*w);                                                 // (clears the plan too)
+    w->table = table; w->tree_slot = tslot; w->twig_slot = bslot;
+    w->tree_pool_len = tl; w->twig_pool_len = bl; w->tree_pool_cap = tc; w->twig_pool_cap = bc;
 
-    int rc = SVO_OK;
+    const size_t n = w->chunks.size();
     do {
-        if (hipMalloc((void **)&w->d_tree, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void **)&w->d_twig, w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
-            hipMalloc((void **)&w->d_mask, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
-            hipMalloc((void **)&w->d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
-            hipMalloc((void **)&w->d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
-            set_error("svo_world_upload: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break;
-        }
-        if (hipMemset(w->d_tree, 0, w->tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
-            hipMemset(w->d_mask, 0, w->twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
-            hipMemset(w->d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); rc = SVO_ERR_HIP; break; }
+        if ((rc = alloc_pools(*w, device)) != SVO_OK) break;
         for (size_t i = 0; i < n && rc == SVO_OK; ++i) {
             const ChunkPools &c = w->chunks[i];
             const DevChunk &e = w->table[i];
@@ -189,7 +240,6 @@ static int world_upload_impl(svo_world *w, int device)
             hipDeviceSynchronize() != hipSuccess) { set_error("svo_world_upload: chunk table copy failed"); rc = SVO_ERR_HIP; break; }
     } while (0);
     if (rc != SVO_OK) { release_device(*w); return rc; }
-    w->occupancy_blocks = 0;
     return SVO_OK;
 }
 
@@ -213,6 +263,7 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
     if (next.size != (float)w->chunksize) { set_error("svo_world_update: chunk size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
     w->chunks[(size_t)chunk].tree.swap(next.tree);
     w->chunks[(size_t)chunk].twig.swap(next.twig);
+    w->chunks[(size_t)chunk].twigs_on_device = 0;       // the caller's bricks replace whatever lived only on the device
     ChunkPools &c = w->chunks[(size_t)chunk];
     std::memcpy(c.position, next.position, sizeof c.position);
     c.size = next.size; c.depth = next.depth;
@@ -237,7 +288,7 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
         const uint64_t tbase = ((w->tree_pool_len + 8) & ~(uint64_t)7) - 1;
         const uint64_t need_t = tree_fits ? 0 : c.tree_capacity, need_b = twig_fits ? 0 : c.twig_capacity;
         if ((!tree_fits && tbase + need_t > w->tree_pool_cap) || (!twig_fits && w->twig_pool_len + need_b > w->twig_pool_cap))
-            return world_upload_impl(w, w->device);
+            return world_upload_impl(w, w->device, true);
         if (!tree_fits) { e.tree_off = tbase; w->tree_slot[(size_t)chunk] = need_t; w->tree_pool_len = tbase + need_t; }
         if (!twig_fits) { e.twig_off = w->twig_pool_len; w->twig_slot[(size_t)chunk] = need_b; w->twig_pool_len += need_b; }
         table_dirty = true;

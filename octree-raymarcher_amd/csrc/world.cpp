@@ -121,8 +121,9 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         p.coarse_depth = tp->coarse_depth;
         for (int i = 0; i < 3; ++i) { p.refine_min[i] = tp->refine_min[i]; p.refine_max[i] = tp->refine_max[i]; }
         if (tp->build_device_plus1 > 0) {
-            const int rc = generate_world_device(tp->build_device_plus1 - 1, w, h, d, chunksize, world->chunkcoordmin, p, world->chunks);
-            if (rc != SVO_OK) { delete world; return rc; }
+            world->terrain = p;
+            const int rc = generate_world_resident(*world, tp->build_device_plus1 - 1);
+            if (rc != SVO_OK) { svo_world_destroy(world); return rc; }
         } else {
             if (generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks) != 0) {
                 delete world;
@@ -247,6 +248,10 @@ int svo_world_info_get(const svo_world *w, svo_world_info *o)
 int svo_world_chunk(const svo_world *w, int i, svo_chunk_desc *o)
 {
     if (!w || !o || i < 0 || i >= (int)w->chunks.size()) return SVO_ERR_INVALID_ARG;
+    if (w->chunks[(size_t)i].twigs_on_device) {         // built on the device: the host copy of the bricks is made on first request
+        const int rc = fetch_bricks(*const_cast<svo_world *>(w), i);
+        if (rc != SVO_OK) return rc;
+    }
     const ChunkPools &c = w->chunks[(size_t)i];
     std::memcpy(o->position, c.position, sizeof o->position);
     o->size = c.size; o->depth = c.depth; o->_pad = 0;

@@ -41,4 +41,11 @@ int  validate_chunk(const ChunkPools &c, std::string &why);
 bool chunk_is_exact(const ChunkPools &c, int chunksize);
 void classify_world(svo_world &w);
 int  release_device(svo_world &w);
+// device.hip: HBM residency building blocks shared by svo_world_upload and the device-resident generator
+int  plan_pools(svo_world &w);                    // slots, offsets and pool sizes from the chunks' capacities (host only)
+int  alloc_pools(svo_world &w, int device);       // hipMalloc + clear of the pools planned above; sets w.device
+int  launch_brick_masks(svo_world &w, uint64_t first, uint64_t count, void *stream);
+int  fetch_bricks(svo_world &w, int chunk);       // bricks that live only on the device -> host copy of that chunk
+// builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
+int  generate_world_resident(svo_world &w, int device);
 } // namespace svo

@@ -1,5 +1,8 @@
-"""Device-side world generation (csrc/builder.hip) must produce pools bit-identical to the host
-builder (which tests/test_scene_parity.py ties to the oracle's restatement of grow / BoundsPyramid / build)."""
+"""Device-side world generation (csrc/builder.hip): noise, min/max mips and grow() as kernels, the water
+fill's brick edits applied in HBM, pools left on the device (the world is uploaded when svo_world_generate returns).
+The pools must be bit-identical to the oracle's restatement of grow / BoundsPyramid / Ocroot::build
+(OracleWorld.generate) and to the host builder's; the march over a device-built world - whose bricks never visited the
+host - must equal the oracle's march over the oracle's world."""
 import time
 
 import numpy as np
@@ -33,6 +36,41 @@ def test_device_built_world_equals_host_built(svo, case):
     H.destroy(); D.destroy()
 
 
+ORACLE_CASES = [
+    dict(w=1, h=1, d=1, depth=2),
+    dict(w=2, h=1, d=2, depth=7),
+    dict(w=2, h=2, d=2, depth=5, chunkcoordmin=(-1, -1, -1)),
+    dict(w=1, h=1, d=1, depth=10),
+    dict(w=1, h=1, d=1, depth=9, water=False),
+]
+
+
+@pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_device_built_world_equals_oracle_generate(svo, oracle, case):
+    """Pools against OracleWorld.generate (the oracle's own World::init), then the march over the device-resident world
+    BEFORE any host copy of the bricks exists against the oracle's march over its own world."""
+    c = dict(case)
+    w, h, d, depth = c.pop("w"), c.pop("h"), c.pop("d"), c.pop("depth")
+    ccm = c.get("chunkcoordmin", (0, 0, 0))
+    O = oracle.OracleWorld.generate(w, h, d, 128, depth, chunkcoordmin=ccm, water=c.get("water", True))
+    D = svo.World.generate(w, h, d, 128, depth, build_device=0, **c)
+    assert D.info.uploaded_device == 0                              # resident: no svo_world_upload needed
+    cam = svo.make_camera((ccm[0] * 128 + w * 64.0 + 0.3, ccm[1] * 128 + 150.0, ccm[2] * 128 - 40.0), (0.0, -0.5, 0.866), (0.0, 1.0, 0.0), 60.0, 320, 180)
+    from helpers import assert_gbuffer_equal
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(D.draw(cam, shadow=True, kernel=k), want, f"march over the device-resident world / kernel {k}")
+    D.upload(0)                                                     # a no-op on the device it was built on
+    assert_gbuffer_equal(D.draw(cam, shadow=True), want, "after upload()")
+    for i in range(w * h * d):
+        a, b = O.chunk(i), D.chunk(i, copy=False)                   # first request: the bricks are fetched from HBM
+        assert tuple(a["position"]) == tuple(b["position"]) and a["depth"] == b["depth"]
+        assert np.array_equal(a["tree"], b["tree"]), f"chunk {i}: node words differ from the oracle's"
+        assert np.array_equal(a["twig"], b["twig"]), f"chunk {i}: bricks differ from the oracle's"
+    assert_gbuffer_equal(D.draw(cam, shadow=True), want, "after the host copy was made")
+    D.destroy()
+
+
 def test_device_builder_c3_world_and_speed(svo):
     """The benchmark world (4x1x4 chunks, depth 12): identical pools; report both generation times."""
     t0 = time.time(); H = svo.World.generate(4, 1, 4, 128, 12); th = time.time() - t0
@@ -41,5 +79,5 @@ def test_device_builder_c3_world_and_speed(svo):
     for i in range(16):
         a, b = H.chunk(i, copy=False), D.chunk(i, copy=False)
         assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
-    print(f"\nC3 world generation: host threads {th:.2f} s, device builder {td:.2f} s")
+    print(f"\nC3 world generation: host threads {th:.2f} s (+ upload), device builder {td:.2f} s (resident: generate + upload)")
     H.destroy(); D.destroy()
