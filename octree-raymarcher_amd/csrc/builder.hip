@@ -477,6 +477,7 @@ static int generate_world_resident_impl(svo_world &w, int device)
         (void)hipFree(bricks[i]); bricks[i] = nullptr;
     }
     BUILD_TRY(hipMemcpy(w.d_chunks, w.table.data(), chunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice));
+    if ((rc = build_wide_all(w, s)) != SVO_OK) return rc;
     BUILD_TRY(hipDeviceSynchronize());
     return SVO_OK;
 }

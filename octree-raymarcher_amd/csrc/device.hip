@@ -27,6 +27,7 @@
 
 #include "kernel_literal.hip.h"
 #include "kernel_stack.hip.h"
+#include "wide_tree.hip.h"
 #include "world.h"
 
 using namespace svo;
@@ -77,13 +78,16 @@ int release_device(svo_world &w)
         (void)hipSetDevice(w.device);
         (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
         (void)hipFree(w.d_mask); (void)hipFree(w.d_work);
+        (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch);
         for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
     }
     w.work_event.clear();
     w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_work = nullptr;
+    w.d_wide = nullptr; w.d_wref = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
     w.device = -1;
-    w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear();
+    w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear(); w.wtable.clear(); w.wide_slot.clear();
     w.tree_pool_len = w.twig_pool_len = w.tree_pool_cap = w.twig_pool_cap = 0;
+    w.wide_pool_len = w.wide_pool_cap = 0;
     return SVO_OK;
 }
 
@@ -142,7 +146,8 @@ int plan_pools(svo_world &w)
         if (c.size != (float)w.chunksize) { set_error("svo_world_upload: every chunk's size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
     const size_t n = w.chunks.size();
     w.table.assign(n, DevChunk());
-    w.tree_slot.assign(n, 0); w.twig_slot.assign(n, 0);
+    w.wtable.assign(n, DevWide());
+    w.tree_slot.assign(n, 0); w.twig_slot.assign(n, 0); w.wide_slot.assign(n, 0);
     uint64_t tcur = 0, bcur = 0;
     for (size_t i = 0; i < n; ++i) {
         const ChunkPools &c = w.chunks[i];
@@ -173,6 +178,7 @@ int alloc_pools(svo_world &w, int device)
         hipMalloc((void **)&w.d_twig, w.twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_mask, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
+        hipMalloc((void **)&w.d_wchunks, n * sizeof(DevWide)) != hipSuccess ||
         hipMalloc((void **)&w.d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
         set_error("svo_world_upload: hipMalloc failed"); return SVO_ERR_OUT_OF_MEMORY;
     }
@@ -180,6 +186,7 @@ int alloc_pools(svo_world &w, int device)
         hipMemset(w.d_mask, 0, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(w.d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); return SVO_ERR_HIP; }
     w.occupancy_blocks = 0;
+    w.wide_ok = false;                                                  // until build_wide_all has run
     return SVO_OK;
 }
 
@@ -194,6 +201,148 @@ int fetch_bricks(svo_world &w, int chunk)
     c.twig.resize(n * TWIG_WORDS);
     HIP_TRY(hipMemcpy(c.twig.data(), w.d_twig + w.table[(size_t)chunk].twig_off * TWIG_WORDS, n * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost));
     c.twigs_on_device = 0;
+    return SVO_OK;
+}
+
+// The wide tree of chunk `chunk` (wide_tree.hip.h) from its node words in the tree pool, level by level, into
+// wide_dst / wref_dst (room for slot_cap wide nodes); *count = wide nodes written.
+static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *wide_dst, uint32_t *wref_dst, uint64_t slot_cap, uint64_t *count_out)
+{
+    const ChunkPools &c = w.chunks[(size_t)chunk];
+    const DevChunk &e = w.table[(size_t)chunk];
+    const uint32_t levels = c.depth - TWIG_LEVELS;
+    const uint32_t nw = levels == 0 ? 1u : (levels + 1u) / 2u;
+    const int pad = (int)(2u * nw - levels);
+    const uint64_t B = c.tree.size() / 8 + 1;                           // most BRANCH nodes (= wide nodes) a level can have
+    uint32_t *front = w.d_wscratch, *next = front + B, *flag = next + B, *rank = flag + 64 * B;
+    const uint32_t *tree = w.d_tree + e.tree_off;
+    HIP_TRY(hipMemsetAsync(front, 0, sizeof(uint32_t), s));             // the top wide node expands reference node 0
+    uint32_t count = 1, first = 0;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = SVO_OK;
+    for (uint32_t k = 0; k < nw && count > 0; ++k) {
+        if ((uint64_t)first + count > slot_cap) { set_error("wide tree: slot overflow"); rc = SVO_ERR_MALFORMED_TREE; break; }
+        const uint32_t n = count * 64u;
+        hipLaunchKernelGGL(k_wide_expand, dim3((n + 255) / 256), dim3(256), 0, s, tree, front, count, first,
+                           k == 0 ? pad : 0, 2u * k + 1u - (uint32_t)pad, wide_dst, wref_dst, flag);
+        if (hipGetLastError() != hipSuccess) { set_error("wide tree: launch failed"); rc = SVO_ERR_HIP; break; }
+        if (k + 1 == nw) { first += count; count = 0; break; }         // grandchildren of the last wide level are never BRANCH
+        size_t bytes = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag, rank, (int)n, s) != hipSuccess) { rc = SVO_ERR_HIP; break; }
+        if (bytes > tmp_bytes) {
+            if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); tmp = nullptr; }
+            if (hipMalloc(&tmp, bytes + 256) != hipSuccess) { set_error("wide tree: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break; }
+            tmp_bytes = bytes + 256;
+        }
+        uint32_t tail[2] = { 0, 0 };
+        if (hipcub::DeviceScan::ExclusiveSum(tmp, bytes, flag, rank, (int)n, s) != hipSuccess ||
+            hipMemcpyAsync(&tail[0], rank + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&tail[1], flag + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { set_error("wide tree: scan failed"); rc = SVO_ERR_HIP; break; }
+        const uint32_t total = tail[0] + tail[1];
+        if ((uint64_t)total > B) { set_error("wide tree: more BRANCH nodes than the tree can hold"); rc = SVO_ERR_MALFORMED_TREE; break; }
+        if (total) {
+            hipLaunchKernelGGL(k_wide_link, dim3((n + 255) / 256), dim3(256), 0, s, count, first, first + count, flag, rank, wide_dst, wref_dst, next);
+            if (hipGetLastError() != hipSuccess) { rc = SVO_ERR_HIP; break; }
+        }
+        first += count; count = total;
+        std::swap(front, next);
+    }
+    (void)hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    if (rc == SVO_OK && count_out) *count_out = first;
+    return rc;
+}
+
+// scratch for the builder: fronts, flags, ranks of the largest chunk, and (count pass) a throw-away wide tree of its bound
+static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
+{
+    const uint64_t B = largest_tree / 8 + 1;
+    const uint64_t need = 2 * B + 2 * 64 * B + 2 * 64 * B + 1024;
+    if (need <= w.wscratch_words) return SVO_OK;
+    if (w.d_wscratch) { (void)hipDeviceSynchronize(); (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; }
+    if (hipMalloc((void **)&w.d_wscratch, need * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipMalloc of the builder scratch failed"); return SVO_ERR_OUT_OF_MEMORY; }
+    w.wscratch_words = need;
+    return SVO_OK;
+}
+static bool wide_fits(const svo_world &w, int chunk)
+{
+    const ChunkPools &c = w.chunks[(size_t)chunk];
+    return c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && c.tree.size() / 8 + 1 <= (uint64_t)WIDE_PAYLOAD_MASK;
+}
+
+// Wide trees of every chunk: a count pass into scratch sizes the pool (each chunk's slot = its wide nodes + 25 % + 16),
+// the build pass writes them in place.  The node words must already be in the tree pool.
+int build_wide_all(svo_world &w, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = w.chunks.size();
+    w.wide_ok = true;
+    uint64_t largest = 0;
+    for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree.size()); if (!wide_fits(w, (int)i)) w.wide_ok = false; }
+    (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); w.d_wide = w.d_wref = nullptr;
+    w.wtable.assign(n, DevWide()); w.wide_slot.assign(n, 0);
+    w.wide_pool_len = w.wide_pool_cap = 0;
+    if (!w.wide_ok) return SVO_OK;                                      // the literal kernel marches such a world
+    int rc = reserve_wide_scratch(w, largest);
+    if (rc != SVO_OK) return rc;
+    const uint64_t Bmax = largest / 8 + 1;
+    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
+    uint64_t cur = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t count = 0;
+        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) return rc;
+        const DevChunk &e = w.table[i];
+        DevWide &v = w.wtable[i];
+        v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
+        v.levels = e.levels; v.wide_off = (uint32_t)cur; v._pad = 0; v.twig_off = e.twig_off;
+        w.wide_slot[i] = count + count / 4 + 16;
+        cur += w.wide_slot[i];
+    }
+    w.wide_pool_len = cur;
+    w.wide_pool_cap = cur + cur / 4 + 64;
+    if (w.wide_pool_cap * 64 >= (1ull << 30)) { w.wide_ok = false; return SVO_OK; }         // 32-bit byte offsets into the pool
+    if (hipMalloc((void **)&w.d_wide, w.wide_pool_cap * 64 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_wref, w.wide_pool_cap * 64 * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY; }
+    for (size_t i = 0; i < n; ++i) {
+        const DevWide &v = w.wtable[i];
+        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wref + (uint64_t)v.wide_off * 64, w.wide_slot[i], nullptr)) != SVO_OK) return rc;
+    }
+    HIP_TRY(hipMemcpy(w.d_wchunks, w.wtable.data(), n * sizeof(DevWide), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+// One chunk again after an edit: in place if its wide tree still fits the slot, at the pool's tail if that has room,
+// otherwise everything is rebuilt.
+int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!w.wide_ok || !wide_fits(w, chunk)) return build_wide_all(w, stream);
+    const ChunkPools &c = w.chunks[(size_t)chunk];
+    uint64_t largest = 0;
+    for (const ChunkPools &k : w.chunks) largest = std::max<uint64_t>(largest, k.tree.size());
+    int rc = reserve_wide_scratch(w, largest);
+    if (rc != SVO_OK) return rc;
+    const uint64_t Bmax = largest / 8 + 1;
+    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
+    uint64_t count = 0;
+    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wref, c.tree.size() / 8 + 1, &count)) != SVO_OK) return rc;
+    DevWide &v = w.wtable[(size_t)chunk];
+    const DevChunk &e = w.table[(size_t)chunk];
+    if (count > w.wide_slot[(size_t)chunk]) {
+        const uint64_t want = count + count / 4 + 16;
+        if (w.wide_pool_len + want > w.wide_pool_cap) return build_wide_all(w, stream);
+        v.wide_off = (uint32_t)w.wide_pool_len;
+        w.wide_slot[(size_t)chunk] = want;
+        w.wide_pool_len += want;
+    }
+    v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
+    v.levels = e.levels; v.twig_off = e.twig_off;
+    HIP_TRY(hipMemcpyAsync(w.d_wide + (uint64_t)v.wide_off * 64, tmp_wide, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.d_wref + (uint64_t)v.wide_off * 64, tmp_wref, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.d_wchunks + chunk, &v, sizeof(DevWide), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SVO_OK;
 }
 
@@ -235,6 +384,7 @@ static int world_upload_impl(svo_world *w, int device, bool force = false)
                 hipMemcpy(w->d_twig + e.twig_off * TWIG_WORDS, c.twig.data(), c.twig.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = SVO_ERR_HIP;
             if (rc == SVO_OK) rc = launch_masks(*w, e.twig_off, c.twig_count(), nullptr);
         }
+        if (rc == SVO_OK) rc = build_wide_all(*w, nullptr);
         if (rc != SVO_OK) { if (rc == SVO_ERR_HIP) set_error("svo_world_upload: copy failed"); break; }
         if (hipMemcpy(w->d_chunks, w->table.data(), n * sizeof(DevChunk), hipMemcpyHostToDevice) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) { set_error("svo_world_upload: chunk table copy failed"); rc = SVO_ERR_HIP; break; }
@@ -306,6 +456,9 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
         if (rc != SVO_OK) return rc;
     }
     if (table_dirty) HIP_TRY(hipMemcpy(w->d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
+    // the stack kernel's view of the chunk: rebuilt from the node words now in the pool
+    rc = rebuild_wide_chunk(*w, chunk, nullptr);
+    if (rc != SVO_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return SVO_OK;
 }
@@ -348,6 +501,7 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
         A.cbase[a] = (dims[a] + (w->chunkcoordmin[a] % dims[a])) % dims[a];
     }
     A.chunks = w->d_chunks; A.tree = w->d_tree; A.twig = w->d_twig; A.mask = w->d_mask;
+    A.wchunks = w->d_wchunks; A.wide = w->d_wide; A.wref = w->d_wref;
     A.eps = (prm && prm->eps != 0.0f) ? prm->eps : 1.0f / 8192.0f;
     A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
     A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;
@@ -369,12 +523,12 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
 static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const TraceArgs &A)
 {
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
-    // the stack kernel addresses nodes by a 32-bit byte offset into the tree pool: pools of 2^30 nodes and more (4 GiB;
-    // the benchmark world has 0.1 G nodes) are marched by the literal kernel
-    const bool stack_ok = w->exact_geometry && w->max_levels <= 16 && w->tree_pool_cap < (1ull << 30);
+    // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
+    // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
+    const bool stack_ok = w->exact_geometry && w->max_levels <= 16 && w->wide_ok;
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
-        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, depth <= 18 and a tree pool below 2^30 nodes"); return SVO_ERR_UNSUPPORTED; }
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, depth <= 18 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }

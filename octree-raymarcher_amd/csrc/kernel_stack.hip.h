@@ -115,6 +115,15 @@ __device__ __forceinline__ uint32_t ld_node(const uint32_t *pool, uint32_t boff)
 {
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pool) + (size_t)boff);
 }
+// entry of a wide node (wide_tree.hip.h) for the cell (ux, uy, uz): its two coordinate bits at `sh` per axis, x lowest
+constexpr uint32_t WIDE_PAYLOAD = (1u << 26) - 1u;
+__device__ __forceinline__ uint32_t wide_slot(int ux, int uy, int uz, int sh)
+{
+    const uint32_t bx = __builtin_amdgcn_ubfe((uint32_t)ux, (uint32_t)sh, 2u);
+    const uint32_t by = __builtin_amdgcn_ubfe((uint32_t)uy, (uint32_t)sh, 2u);
+    const uint32_t bz = __builtin_amdgcn_ubfe((uint32_t)uz, (uint32_t)sh, 2u);
+    return (bz << 4) | (by << 2) | bx;
+}
 // type == BRANCH (binary 10 in the top bits) as one signed comparison
 __device__ __forceinline__ bool is_branch(uint32_t word) { return (int32_t)word < (int32_t)0xC0000000; }
 
@@ -187,7 +196,7 @@ __device__ SVO_NEST_INLINE float brick_layer_first_touch(int k, V3 a, V3 b, V3 g
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
-    __shared__ uint32_t stk[MAXLV > 0 ? MAXLV : 1][64];
+    __shared__ uint32_t stk[MAXLV / 2 + 1][64];     // wide node index per wide level of the current path (level 0 is node 0)
     __shared__ float tile_ray[11][64];              // o, d, 1/d, world-entry t, output index (as int; -1 = no ray)
     const int lane = threadIdx.x;
 #ifdef SVO_STACK_TIMING
@@ -238,11 +247,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     int it_saved = 0;
     // chunk
     V3 clo = mk(0, 0, 0);
-    uint32_t tree_b = 0;            // byte offset of the chunk's node 0 in the tree pool
+    uint32_t wide_b = 0;            // byte offset of the chunk's top wide node in the wide pool
     uint32_t twig_off = 0;
     int levels = 0, ci = -1;
     // descent cache: cell coordinates of the last tree step and the level of the node it ended at
-    int pux = 0, puy = 0, puz = 0, valid = 0;
+    // (valid: deepest wide level whose node index is cached; plev: reference level of the node the last tree step ended at)
+    int pux = 0, puy = 0, puz = 0, valid = 0, plev = 0;
     // brick
     unsigned long long bmask = 0;
     // creeping rays: |creepn| = consecutive advances of this ray by less than 2 EPS (kept across level changes: a ray pinned
@@ -377,11 +387,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     // tile, a ray pinned on a chunk face - restarts below the deepest common level instead of at the root.
                     if (ci_new != ci) valid = 0;
                     ci = ci_new;
-                    const DevChunk ch = A.chunks[ci];
+                    const DevWide ch = A.wchunks[ci];
                     clo = ld3(ch.bmin);
                     miss = !inside(p, clo, clo + csize);
                     if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
-                        tree_b = (uint32_t)ch.tree_off << 2;
+                        wide_b = ch.wide_off << 8;                   // 64 entries of 4 bytes per wide node
                         twig_off = (uint32_t)ch.twig_off;
                         levels = (int)ch.levels;
                         O = p; t = 0.0f; cnt = 0;
@@ -433,29 +443,27 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             uint32_t payload = 0;                                   // node word (tree) / cell index (brick)
             if (!leave) {
                 if (!twig) {
-                    // descend from the deepest cached level whose coordinate prefix is unchanged
+                    // descend through the chunk's wide tree (wide_tree.hip.h: two reference levels per node) from the
+                    // deepest cached wide level whose node is unchanged: wide level k is selected by the coordinate bits
+                    // above 2 (nw - k), so it survives while the highest differing bit lies below that
                     const uint32_t diff = (uint32_t)((ux ^ pux) | (uy ^ puy) | (uz ^ puz));
-                    const int common = levels - (diff ? 32 - __clz((int)diff) : 0);
-                    const int usable = common + 1 < valid ? common + 1 : valid;
-                    uint32_t node = 0;
-                    int sh = levels - 1;                            // bit of the cell coordinates that selects the child
-                    if (usable > 0) {
-                        sh = levels - usable;
-                        node = stk[usable - 1][lane] + child_slot(ux, uy, uz, sh);
-                        --sh;
-                    }
-                    uint32_t word = ld_node(A.tree, tree_b + (node << 2));
-                    // No level test: svo_world_create / svo_world_update reject a reachable BRANCH below level depth-2
-                    // (validate_chunk), so the walk ends at or above the last level.
+                    const int nw = levels ? (levels + 1) >> 1 : 1;
+                    const int hb = diff ? 32 - __clz((int)diff) : 0;
+                    const int keep = nw - ((hb + 1) >> 1);
+                    int k = keep < valid ? keep : valid;
+                    uint32_t wnode = k > 0 ? stk[k][lane] : 0u;
+                    int sh = 2 * (nw - 1 - k);                      // the two coordinate bits that select the entry
+                    uint32_t word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
                     while (is_branch(word)) {
-                        const uint32_t base = node_offset(word);
-                        stk[levels - 1 - sh][lane] = base;
-                        node = base + child_slot(ux, uy, uz, sh);
-                        --sh;
-                        word = ld_node(A.tree, tree_b + (node << 2));
+                        wnode = word & WIDE_PAYLOAD;
+                        ++k;
+                        stk[k][lane] = wnode;
+                        sh -= 2;
+                        word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
                     }
-                    valid = levels - 1 - sh; pux = ux; puy = uy; puz = uz;
-                    low = (1 << (sh + 1)) - 1;                      // the node spans 2^(levels - level) cells
+                    valid = k; pux = ux; puy = uy; puz = uz;
+                    plev = (int)((word >> 26) & 15u);               // the reference node's level: it spans 2^(levels - level) cells
+                    low = (1 << (levels - plev)) - 1;
                     const uint32_t type = node_type(word);
                     what = type == EMPTY ? S_ADVANCE : type == LEAF ? S_HIT_LEAF : S_ENTER;
                     payload = word;
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 }
             }
             if (what == S_ENTER) {                                  // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
-                bmask = A.mask[twig_off + node_offset(payload)];
+                bmask = A.mask[twig_off + (payload & WIDE_PAYLOAD)];
                 tt_saved = t; it_saved = cnt;
                 O = p; t = 0.0f; cnt = 0;
                 Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     lo = Blo; size = Bsize;
                     go &= (q0.x == O.x) & (q0.y == O.y) & (q0.z == O.z);
                 } else if (!twig) {                                 // the EMPTY node located by the last tree step
-                    const int low = (1 << (levels - valid)) - 1;
+                    const int low = (1 << (levels - plev)) - 1;
                     lo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
                     size = res * (float)(low + 1);
                 } else {                                            // the brick cell q0 lies in, if it is an empty one
@@ -664,24 +672,23 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
         if (run_hit && mode == M_HIT) {
             // which voxel: the node comes from the descent cache; the frame still describes the level that hit
-            const int sh = levels - valid;
-            const uint32_t node = valid > 0
-                ? stk[valid - 1][lane] + (uint32_t)(((pux >> sh) & 1) | (((puy >> sh) & 1) << 1) | (((puz >> sh) & 1) << 2))
-                : 0u;
-            const uint32_t word = ld_node(A.tree, tree_b + (node << 2));
+            const int nw = levels ? (levels + 1) >> 1 : 1;
+            const uint32_t at = wide_b + ((((valid > 0 ? stk[valid][lane] : 0u) << 6) + wide_slot(pux, puy, puz, 2 * (nw - 1 - valid))) << 2);
+            const uint32_t word = ld_node(A.wide, at);              // the terminal entry again (material / brick index) ...
+            const uint32_t node = ld_node(A.wref, at);              // ... and the reference node it stands for (svo_hit.node)
             const uint32_t hitc = (uint32_t)cnt;                    // which brick cell (or SVO_CELL_NONE: a LEAF)
             V3 vlo;
             float vsize;
             uint32_t material;
             if (hitc == SVO_CELL_NONE) {                            // LEAF node: frame = tree level (Blo = clo, res = cell)
-                const int low = (1 << sh) - 1;
+                const int low = (1 << (levels - plev)) - 1;
                 vlo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
                 vsize = res * (float)(low + 1);
-                material = node_offset(word) & 0xFFFFu;
+                material = word & 0xFFFFu;
             } else {                                                // brick cell: frame = brick (Blo = node box, res = voxel)
                 vlo = mk(Blo.x + (float)(hitc & 3u) * res, Blo.y + (float)((hitc >> 2) & 3u) * res, Blo.z + (float)(hitc >> 4) * res);
                 vsize = res;
-                material = A.twig[((unsigned long long)twig_off + node_offset(word)) * TWIG_WORDS + hitc];
+                material = A.twig[((unsigned long long)twig_off + (word & WIDE_PAYLOAD)) * TWIG_WORDS + hitc];
             }
             const V3 point = alpha + beta * (tw - eps);
             const bool face = A.normal_mode == SVO_NORMAL_FACE;

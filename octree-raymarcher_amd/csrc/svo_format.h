@@ -34,6 +34,16 @@ struct DevChunk {               // 32 bytes
 };
 static_assert(sizeof(DevChunk) == 32, "chunk table entry is 32 bytes");
 
+// The stack kernel's chunk table: the same 32 bytes with the chunk's wide tree (wide_tree.hip.h) in place of tree[].
+struct DevWide {
+    float    bmin[3];
+    uint32_t levels;
+    uint32_t wide_off;          // index of the chunk's top wide node in the wide pool (64 uint32 entries per wide node)
+    uint32_t _pad;
+    uint64_t twig_off;
+};
+static_assert(sizeof(DevWide) == 32, "wide chunk table entry is 32 bytes");
+
 // Everything a trace kernel needs, passed by value.
 // Launch slot (u64 words).  The stack kernel deals the image out as TILE_REGIONS screen regions, one per XCD (own L2),
 // each with its own cursor; a wave whose region is empty moves on to the next one.
@@ -52,6 +62,9 @@ struct TraceArgs {
     float    chunksize;
     int32_t  dimw, dimh, dimd;
     const DevChunk *chunks;
+    const DevWide  *wchunks;    // stack kernel: chunk table over the wide pool
+    const uint32_t *wide;       // wide pool: 64 entries per wide node (wide_tree.hip.h)
+    const uint32_t *wref;       // reference node index of every wide entry (for svo_hit.node)
     const uint32_t *tree;
     const uint16_t *twig;
     const uint64_t *mask;

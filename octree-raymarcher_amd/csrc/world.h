@@ -24,6 +24,14 @@ struct svo_world {
     uint32_t *d_tree = nullptr;
     uint16_t *d_twig = nullptr;
     uint64_t *d_mask = nullptr;
+    uint32_t *d_wide = nullptr, *d_wref = nullptr;  // wide tree of every chunk (wide_tree.hip.h) and its reference node indices
+    svo::DevWide *d_wchunks = nullptr;
+    std::vector<svo::DevWide> wtable;             // host mirror of d_wchunks
+    std::vector<uint64_t> wide_slot;              // capacity of each chunk's wide slot (wide nodes)
+    uint64_t wide_pool_len = 0, wide_pool_cap = 0;
+    uint32_t *d_wscratch = nullptr;               // builder scratch: fronts, flags, ranks
+    uint64_t wscratch_words = 0;
+    bool wide_ok = false;                         // every chunk's bricks fit the 26-bit payload
     unsigned long long *d_work = nullptr;         // WORK_SLOTS x {tile cursor, rays marched}: one slot per launch in flight
     unsigned work_next = 0, work_last = 0;        // ring cursor; slot of the most recent launch
     std::vector<void *> work_event;               // hipEvent_t per slot, recorded behind the launch that used it
@@ -46,6 +54,7 @@ int  plan_pools(svo_world &w);                    // slots, offsets and pool siz
 int  alloc_pools(svo_world &w, int device);       // hipMalloc + clear of the pools planned above; sets w.device
 int  launch_brick_masks(svo_world &w, uint64_t first, uint64_t count, void *stream);
 int  fetch_bricks(svo_world &w, int chunk);       // bricks that live only on the device -> host copy of that chunk
+int  build_wide_all(svo_world &w, void *stream);  // wide trees (wide_tree.hip.h) of all chunks from the node words in the tree pool
 // builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
 int  generate_world_resident(svo_world &w, int device);
 } // namespace svo
