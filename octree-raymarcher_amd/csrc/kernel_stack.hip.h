@@ -410,6 +410,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // ---- one step of the current level: tree (src/Traverse.cpp:79-111) or brick (:54-70) -----
         //      First decide what the step does (locate the cell, read its node / mask bit), then apply exactly one of
         //      the outcomes below as a flat sequence of predicated updates of the lane state.
+        //      The step repeats at once, without the refill / vote / block checks around it, while every live lane of the
+        //      wave is marching and nothing else can be due: that is the state of the waves that carry a launch's longest
+        //      rays after the tile cursors ran dry, alone on their SIMD and bound by their own instruction stream.
+        bool again;
+        do {
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
@@ -516,6 +521,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 mode = M_HIT;
             }
         }
+
+        {
+            const unsigned long long marching = __ballot(mode == M_TREE || mode == M_TWIG);
+            again = !more && marching != 0ull && marching == __ballot(mode != M_DONE) && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull;
+            if (again && ++guard > STEP_GUARD) again = false;       // (the general path flags the runaway ray)
+        }
+        } while (again);
 
         // ---- creep block.  A ray that sits exactly on a lattice plane (p.a == lo.a of its cell) and moves towards the
         //      negative side of axis a by less than one ulp per step gets cubeEscapeDistance == -0 and advances by EPS
