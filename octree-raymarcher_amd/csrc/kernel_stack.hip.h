@@ -15,10 +15,11 @@
 //    body every lane runs in one of three modes, sharing one escape-distance evaluation.
 //  * Descent: the position inside the chunk is reduced to integer cell coordinates at level
 //    depth-2 (one exact compare-and-fix per axis reproduces the reference's float `p >= mid`
-//    tests).  The children-base index of every BRANCH on the current root->node path is cached
-//    in a per-lane LDS column ([level][lane]: bank = lane, conflict-free).  The next step
-//    restarts below the deepest level whose cell prefix is unchanged: ~1-3 dependent node loads
-//    per step instead of one per level.
+//    tests) and looked up in the chunk's WIDE tree (wide_tree.hip.h: built on upload from tree[], 64 entries per node
+//    = two reference levels per dependent load).  The wide node of every wide level of the current path is cached in
+//    a per-lane LDS column ([level][lane]: bank = lane, conflict-free); the next step restarts at the deepest level
+//    whose coordinate prefix is unchanged - and keeps the cache across rays of the same chunk (a shadow ray starts
+//    where its primary ray ended): ~1.4 dependent loads per tree step instead of one per level.
 //  * Bricks are tested against a 64-bit occupancy mask held in registers (one 8-byte load per
 //    brick visit); the 128-byte brick line is touched only to fetch the hit material.
 //  * Ray generation (camera ray, 1/dir, world-entry distance: ~10 IEEE divisions) is done once per
@@ -26,6 +27,10 @@
 //    waves can refill after only a few retirements.
 //  * The rare, expensive blocks (chunk step, G-buffer resolve of a primary hit) run only when a
 //    ballot shows enough lanes waiting for them (or nothing else is runnable).
+//  * Creeping rays - pinned on a lattice plane, advancing by EPS alone for thousands of steps, alone or nested over a
+//    brick whose marches are bound to miss - are taken in closed form by a vote-gated block (same t, same counters).
+//  * Once the tile cursors are dry and every live lane is marching, the step repeats without the refill / vote / block
+//    checks around it: a launch's last waves are alone on their SIMD and bound by their own instruction stream.
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
 //    reference's own expressions instead of being held): 96 VGPRs, 5 waves per SIMD.
 //
