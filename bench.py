@@ -539,7 +539,8 @@ def run(args):
                 "camera_path": {"kind": args.camera_path, "cameras": P, "rays_per_frame_min": min(rays_cam), "rays_per_frame_max": max(rays_cam),
                                 "note": "frame i is seen by camera i mod P; camera 0 = SURVEY §8d view (eye on the chunk seam), the others off the voxel lattice, the last one the grazing view"},
                 "nodes": int(info.total_trees), "bricks": int(info.total_twigs),
-                "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes),
+                "hbm_pool_bytes": int(info.tree_pool_bytes + info.twig_pool_bytes + info.mask_pool_bytes + info.wide_pool_bytes),
+                "wide_tree": {"nodes": int(info.wide_nodes), "pool_bytes": int(info.wide_pool_bytes)},
                 "kernel": args.kernel, "launches_in_flight": S, "frames_per_launch": G, "frames_in_flight": S * G,
                 "backend": args.backend if multi else None, "gather": bool(multi and not args.no_gather),
                 "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",

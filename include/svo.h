@@ -192,6 +192,8 @@ typedef struct svo_world_info {
     uint64_t tree_pool_bytes, twig_pool_bytes, mask_pool_bytes;
     int32_t  max_chunk_depth;
     int32_t  exact_geometry;        /* 1: all voxel corners are exact floats -> SVO_KERNEL_STACK allowed */
+    uint64_t wide_pool_bytes;       /* the stack kernel's derived view of the trees (two levels per node) + its reference node indices */
+    uint64_t wide_nodes;            /* wide nodes in use (64 entries each) */
 } svo_world_info;
 
 /* ---- world construction (host) ------------------------------------------------------------ */

@@ -115,7 +115,8 @@ class WorldInfo(C.Structure):
                 ("chunkcoordmin", C.c_int32 * 3), ("uploaded_device", C.c_int32),
                 ("total_trees", C.c_uint64), ("total_twigs", C.c_uint64),
                 ("tree_pool_bytes", C.c_uint64), ("twig_pool_bytes", C.c_uint64), ("mask_pool_bytes", C.c_uint64),
-                ("max_chunk_depth", C.c_int32), ("exact_geometry", C.c_int32)]
+                ("max_chunk_depth", C.c_int32), ("exact_geometry", C.c_int32),
+                ("wide_pool_bytes", C.c_uint64), ("wide_nodes", C.c_uint64)]
 
 
 # every symbol include/svo.h declares (tests check that the library exports exactly these)

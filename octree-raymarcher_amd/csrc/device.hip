@@ -283,7 +283,7 @@ int build_wide_all(svo_world &w, void *stream)
     for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree.size()); if (!wide_fits(w, (int)i)) w.wide_ok = false; }
     (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); w.d_wide = w.d_wref = nullptr;
     w.wtable.assign(n, DevWide()); w.wide_slot.assign(n, 0);
-    w.wide_pool_len = w.wide_pool_cap = 0;
+    w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
     if (!w.wide_ok) return SVO_OK;                                      // the literal kernel marches such a world
     int rc = reserve_wide_scratch(w, largest);
     if (rc != SVO_OK) return rc;
@@ -299,6 +299,7 @@ int build_wide_all(svo_world &w, void *stream)
         v.levels = e.levels; v.wide_off = (uint32_t)cur; v._pad = 0; v.twig_off = e.twig_off;
         w.wide_slot[i] = count + count / 4 + 16;
         cur += w.wide_slot[i];
+        w.wide_nodes_used += count;
     }
     w.wide_pool_len = cur;
     w.wide_pool_cap = cur + cur / 4 + 64;

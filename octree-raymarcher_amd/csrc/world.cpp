@@ -242,6 +242,8 @@ int svo_world_info_get(const svo_world *w, svo_world_info *o)
     o->mask_pool_bytes = w->twig_pool_cap * sizeof(uint64_t);
     o->max_chunk_depth = w->max_levels + (int)TWIG_LEVELS;
     o->exact_geometry = w->exact_geometry ? 1 : 0;
+    o->wide_pool_bytes = w->wide_pool_cap * 64 * sizeof(uint32_t) * 2;
+    o->wide_nodes = w->wide_nodes_used;
     return SVO_OK;
 }
 

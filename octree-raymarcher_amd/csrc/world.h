@@ -28,7 +28,7 @@ struct svo_world {
     svo::DevWide *d_wchunks = nullptr;
     std::vector<svo::DevWide> wtable;             // host mirror of d_wchunks
     std::vector<uint64_t> wide_slot;              // capacity of each chunk's wide slot (wide nodes)
-    uint64_t wide_pool_len = 0, wide_pool_cap = 0;
+    uint64_t wide_pool_len = 0, wide_pool_cap = 0, wide_nodes_used = 0;
     uint32_t *d_wscratch = nullptr;               // builder scratch: fronts, flags, ranks
     uint64_t wscratch_words = 0;
     bool wide_ok = false;                         // every chunk's bricks fit the 26-bit payload
