@@ -61,6 +61,13 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #ifndef SVO_CREEP_LANES
 #define SVO_CREEP_LANES 8
 #endif
+// the step runs up to 1 + SVO_STEP_EXTRA times per pass of the outer loop while at least SVO_STEP_LANES lanes are marching
+#ifndef SVO_STEP_EXTRA
+#define SVO_STEP_EXTRA 3
+#endif
+#ifndef SVO_STEP_LANES
+#define SVO_STEP_LANES 16
+#endif
 
 // 1/x for x an exact power of two (normal range): exponent negation, no division sequence.
 __device__ __forceinline__ float recip_pow2(float x) { return __uint_as_float(0x7F000000u - __float_as_uint(x)); }
@@ -419,6 +426,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      wave is marching and nothing else can be due: that is the state of the waves that carry a launch's longest
         //      rays after the tile cursors ran dry, alone on their SIMD and bound by their own instruction stream.
         bool again;
+        int pass = 0;
         do {
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
@@ -530,6 +538,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         {
             const unsigned long long marching = __ballot(mode == M_TREE || mode == M_TWIG);
             again = !more && marching != 0ull && marching == __ballot(mode != M_DONE) && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull;
+            // in the bulk: up to SVO_STEP_EXTRA more steps before the wave looks at refills and votes again, while enough lanes
+            // are marching - the checks around the step cost a quarter of an iteration, the lanes that have to wait for
+            // them a step or two longer cost less
+            if (!again && pass < SVO_STEP_EXTRA && __popcll(marching) >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) again = true;
+            ++pass;
             if (again && ++guard > STEP_GUARD) again = false;       // (the general path flags the runaway ray)
         }
         } while (again);
