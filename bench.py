@@ -60,11 +60,12 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_STREAM_GBS = 6300.0        # ... and what a streaming copy achieves (6.29 TB/s measured)
 BAND = 8                       # rows per band == tile height of the stack kernel
-# 16 frames in flight at N = 1: 2 launches of 8 frames.  A launch ends with a tail (its longest rays, each wave alone on its
-# SIMD); 8 frames behind one set of cursors pay it once instead of twice (measured on the camera path: F x S = 4 x 4 ->
-# 3 719 Mrays/s, launch 5.46 ms; 8 x 2 -> 3 717, 9.24 ms; 16 x 2 -> 3 767, 16.6 ms).  The N > 1 rows come from one-GPU
-# emulation of a rank's share (--emulate-share) and are unmeasured on real multi-GPU hardware.
-STREAMS_FOR_SHARE = {1: 2, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways
+# N = 1: 8 frames per launch, 4 launches in flight.  A launch ends with a tail (its longest rays, each wave alone on its
+# SIMD); 8 frames behind one set of cursors pay it once, and the next launches' bulk runs under it.  Measured on the
+# camera path (final kernel): F x S = 4 x 4 -> 4 239 Mrays/s (launch 4.69 ms), 8 x 2 -> 4 243 (7.93 ms), 8 x 4 -> 4 278;
+# the small frames of C2 need the four launches in flight (6 218 -> 10 167).  The N > 1 rows come from one-GPU emulation
+# of a rank's share (--emulate-share) and are unmeasured on real multi-GPU hardware.
+STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways
 FRAMES_PER_LAUNCH = {1: 8, 2: 8, 4: 16, 8: 16}      # consecutive frames marched by one launch (and shipped by one gather)
 PATH_CAMERAS = 32
 

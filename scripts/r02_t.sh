@@ -1,6 +1,6 @@
 #!/bin/bash
-set -e
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3
-V="base vw4 vw16 vh8 vh32 rf4 rf16 sl8"
-export AB_REPS=2
-echo "== path pipelined"; bash scripts/ab.sh "--steps 200 --warmup 24 --no-diagnostics" $V
+for a in "--streams 2" "--streams 4" "--streams 3" "--streams 4 --frames-per-launch 4"; do
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-diagnostics --steps 256 --warmup 32 $a | python3 -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 $a', r['value'], r['ms_per_step'], r['roofline']['kernel_ms_avg'])"
+done
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-diagnostics --steps 20 --warmup 5 --streams 4| python3 -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 driver shape S=4', r['value'], r['config']['frames_per_launch'])"
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-diagnostics --steps 20 --warmup 5 --streams 2| python3 -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 driver shape S=2', r['value'], r['config']['frames_per_launch'])"
