@@ -29,8 +29,9 @@
 //    ballot shows enough lanes waiting for them (or nothing else is runnable).
 //  * Creeping rays - pinned on a lattice plane, advancing by EPS alone for thousands of steps, alone or nested over a
 //    brick whose marches are bound to miss - are taken in closed form by a vote-gated block (same t, same counters).
-//  * Once the tile cursors are dry and every live lane is marching, the step repeats without the refill / vote / block
-//    checks around it: a launch's last waves are alone on their SIMD and bound by their own instruction stream.
+//  * The step runs up to four times per pass of the outer loop while >= 16 lanes are marching, and keeps repeating once
+//    the tile cursors are dry and every live lane is marching: the refill / vote / block checks around it are a quarter
+//    of an iteration, and a launch's last waves are alone on their SIMD, bound by their own instruction stream.
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
 //    reference's own expressions instead of being held): 96 VGPRs, 5 waves per SIMD.
 //
