@@ -4,7 +4,8 @@
 // dependent-issue latency never gates the stream).  Per wave: s_memtime before and after; cycles per instruction per
 // SIMD = elapsed / (instructions per wave * W) because the W waves of a SIMD share its issue port for that interval.
 // The same figure follows from the launch's wall time (HIP events) and the shader clock.  Mixes measured: v_fma_f32,
-// v_add_u32, v_bfe_u32, v_cmp+v_cndmask (the march step's compare/select pairs), v_mul_f32 + v_cvt.
+// v_add_u32, v_bfe_u32, v_cmp+v_cndmask (the march step's compare/select pairs), v_mul_f32 + v_cvt, and the packed
+// v_pk_mul_f32 / v_pk_add_f32 (two float operations per lane and instruction) the compiler forms from xyz arithmetic.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue > valu_issue.json
 #include <hip/hip_runtime.h>
@@ -15,9 +16,9 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { OP_FMA = 0, OP_ADDU = 1, OP_BFE = 2, OP_CMPSEL = 3, OP_MULCVT = 4, N_OPS = 5 };
-static const char *op_name[N_OPS] = { "v_fma_f32", "v_add_u32", "v_bfe_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_mul_f32+v_cvt_i32_f32" };
-static const int op_insts[N_OPS] = { 1, 1, 1, 2, 2 };     // VALU instructions per "op" below
+enum { OP_FMA = 0, OP_ADDU = 1, OP_BFE = 2, OP_CMPSEL = 3, OP_MULCVT = 4, OP_PKMUL = 5, OP_PKADD = 6, N_OPS = 7 };
+static const char *op_name[N_OPS] = { "v_fma_f32", "v_add_u32", "v_bfe_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_mul_f32+v_cvt_i32_f32", "v_pk_mul_f32", "v_pk_add_f32" };
+static const int op_insts[N_OPS] = { 1, 1, 1, 2, 2, 1, 1 };     // VALU instructions per "op" below
 
 constexpr int UNROLL = 8;       // independent accumulators
 constexpr int INNER = 16;       // ops per accumulator per loop trip (loop overhead: 2 SALU per 128+ VALU)
@@ -27,8 +28,11 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
 {
     float a[UNROLL];
     unsigned u[UNROLL];
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v pk[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) { a[i] = seed + (float)(threadIdx.x + i); u[i] = threadIdx.x * 7u + i; }
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed + (float)(threadIdx.x + i); u[i] = threadIdx.x * 7u + i; pk[i].x = a[i]; pk[i].y = a[i] * 0.5f; }
+    float2v pm; pm.x = 1.0000001f; pm.y = 0.9999999f;
     const float m = 1.0000001f, c = 1e-7f;
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -42,6 +46,8 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
                 if (OP == OP_BFE) asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(u[i]));
                 if (OP == OP_CMPSEL) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(m), "v"(c) : "vcc");
                 if (OP == OP_MULCVT) asm volatile("v_mul_f32 %0, %0, %2\n\tv_cvt_i32_f32 %1, %0" : "+v"(a[i]), "=v"(u[i]) : "v"(m));
+                if (OP == OP_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i]) : "v"(pm));
+                if (OP == OP_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[i]) : "v"(pm));
             }
         }
     }
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f; unsigned q = 0;
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) { s += a[i]; q += u[i]; }
+    for (int i = 0; i < UNROLL; ++i) { s += a[i] + pk[i].x + pk[i].y; q += u[i]; }
     if (s == 12345.678f && q == 42u) sink[0] = s;             // keep the streams alive
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
@@ -98,7 +104,9 @@ int main()
         run<OP_ADDU>(w, ncu, ghz, false);
         run<OP_BFE>(w, ncu, ghz, false);
         run<OP_CMPSEL>(w, ncu, ghz, false);
-        run<OP_MULCVT>(w, ncu, ghz, w == 8);
+        run<OP_MULCVT>(w, ncu, ghz, false);
+        run<OP_PKMUL>(w, ncu, ghz, false);
+        run<OP_PKADD>(w, ncu, ghz, w == 8);
     }
     printf("  ]\n}\n");
     return 0;
