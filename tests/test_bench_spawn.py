@@ -53,3 +53,18 @@ def test_gpus_mismatch_is_refused():
     env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--spawn-selftest"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_trace_pack_gather_on_the_gpu():
+    """The product's N > 1 chain end to end with 2 self-spawned ranks: each rank generates the world on the device, traces its
+    8-row bands (svo_trace_rows_frames), packs them (svo_gbuffer_pack), rank 0 gathers and de-interleaves - and bench.py's
+    mandatory self-check compares the gathered frame with a single-GPU trace of the whole image.  The box has one GPU, so
+    both ranks share it and the exchange is staged through the host over gloo (RCCL refuses two ranks on one device); what
+    runs between the ranks is the same control flow as over RCCL."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--workload", "c3small_1080p_depth10_4x1x4_shadow",
+                        "--steps", "24", "--warmup", "8"], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["gather"] is True
+    assert out["config"]["launcher"] == "self-spawned" and out["value"] > 0 and out["diagnostics"]["trace_only_mrays"] > out["value"]
