@@ -67,7 +67,7 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #define SVO_STEP_EXTRA 3
 #endif
 #ifndef SVO_STEP_LANES
-#define SVO_STEP_LANES 16
+#define SVO_STEP_LANES 8
 #endif
 
 // 1/x for x an exact power of two (normal range): exponent negation, no division sequence.
@@ -210,7 +210,8 @@ template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
     __shared__ uint32_t stk[MAXLV / 2 + 1][64];     // wide node index per wide level of the current path (level 0 is node 0)
-    __shared__ float tile_ray[11][64];              // o, d, 1/d, world-entry t, output index (as int; -1 = no ray)
+    __shared__ float tile_ray[11][64];
+    stk[0][threadIdx.x] = 0u;              // o, d, 1/d, world-entry t, output index (as int; -1 = no ray)
     const int lane = threadIdx.x;
 #ifdef SVO_STACK_TIMING
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
@@ -428,6 +429,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      rays after the tile cursors ran dry, alone on their SIMD and bound by their own instruction stream.
         bool again;
         int pass = 0;
+        // in the bulk: SVO_STEP_EXTRA more steps, decided once per pass of the outer loop (n_busy: before the chunk step)
+        const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? (
+#ifdef SVO_X_DYN
+            n_busy >= SVO_X_DYN ? SVO_STEP_EXTRA + 2 :
+#endif
+            SVO_STEP_EXTRA) : 0;
         do {
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
@@ -467,10 +474,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     // above 2 (nw - k), so it survives while the highest differing bit lies below that
                     const uint32_t diff = (uint32_t)((ux ^ pux) | (uy ^ puy) | (uz ^ puz));
                     const int nw = levels ? (levels + 1) >> 1 : 1;
-                    const int hb = diff ? 32 - __clz((int)diff) : 0;
+                    const int hb = 32 - __clz((int)(diff | 1u));    // (diff == 0 reads as "bit 0 differs": keep = nw - 1 >= valid either way)
                     const int keep = nw - ((hb + 1) >> 1);
                     int k = keep < valid ? keep : valid;
-                    uint32_t wnode = k > 0 ? stk[k][lane] : 0u;
+                    uint32_t wnode = stk[k][lane];                  // (row 0 holds node 0: no branch for k == 0)
                     int sh = 2 * (nw - 1 - k);                      // the two coordinate bits that select the entry
                     uint32_t word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
                     while (is_branch(word)) {
@@ -496,7 +503,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             //      leave: out of the level's own box from its origin (src/Traverse.cpp:104-105 brick, :164-168 chunk)
             if (what <= S_ADVANCE) {
                 const V3 E_p = leave ? O : p;
-                const V3 E_lo = leave ? Blo : mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
+                // (leave: the level's own box as the cell at offset 0 - Blo + 0 * res == Blo up to the sign of a zero, which
+                //  the subtraction of p forgets; one select instead of a branch around the cell's corner)
+                const int keepm = leave ? 0 : ~low;
+                const V3 E_lo = mk(Blo.x + (float)(ux & keepm) * res, Blo.y + (float)(uy & keepm) * res, Blo.z + (float)(uz & keepm) * res);
                 const float E_size = leave ? Bsize : res * (float)(low + 1);
                 const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
                 if (!leave) {
@@ -536,17 +546,19 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
         }
 
-        {
+        // Loop control is wave-uniform (scalar compare and branch).  In the bulk the number of extra steps was fixed before
+        // the loop: nothing is looked at between them - the checks around the step (refill, three votes, guard, creep vote,
+        // hit blocks) cost a quarter of an iteration, even one ballot per step 2 %; the lanes that wait a step or two
+        // longer for a refill or a vote cost less.  The per-lane runaway guard is settled after the loop, which ends
+        // after 256 steps at the latest so that the outer loop's check sees a runaway ray.
+        if (pass < fixed_steps) { again = true; ++pass; }
+        else {
             const unsigned long long marching = __ballot(mode == M_TREE || mode == M_TWIG);
-            again = !more && marching != 0ull && marching == __ballot(mode != M_DONE) && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull;
-            // in the bulk: up to SVO_STEP_EXTRA more steps before the wave looks at refills and votes again, while enough lanes
-            // are marching - the checks around the step cost a quarter of an iteration, the lanes that have to wait for
-            // them a step or two longer cost less
-            if (!again && pass < SVO_STEP_EXTRA && __popcll(marching) >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) again = true;
+            again = !more && marching != 0ull && marching == __ballot(mode != M_DONE) && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull && pass < 256;
             ++pass;
-            if (again && ++guard > STEP_GUARD) again = false;       // (the general path flags the runaway ray)
         }
         } while (again);
+        guard += pass - 1;
 
         // ---- creep block.  A ray that sits exactly on a lattice plane (p.a == lo.a of its cell) and moves towards the
         //      negative side of axis a by less than one ulp per step gets cubeEscapeDistance == -0 and advances by EPS
