@@ -430,11 +430,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         bool again;
         int pass = 0;
         // in the bulk: SVO_STEP_EXTRA more steps, decided once per pass of the outer loop (n_busy: before the chunk step)
-        const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? (
-#ifdef SVO_X_DYN
-            n_busy >= SVO_X_DYN ? SVO_STEP_EXTRA + 2 :
-#endif
-            SVO_STEP_EXTRA) : 0;
+        const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? SVO_STEP_EXTRA : 0;
         do {
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
@@ -578,7 +574,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      returns false, src/Traverse.cpp:97-105): quadratically many steps.  A lane that has just entered a brick
         //      with a creeping history asks whether the whole run of tree steps over this node consists of such misses
         //      (brick_layer_first_touch bounds how far they can go); that run is taken at once, exactly like a run over an EMPTY node.
-        {
+        if (__ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) != 0ull) {      // (what cr and ent below need; most passes: nobody)
             const bool cr = creepn > 0 && (mode == M_TREE || mode == M_TWIG);
 #ifdef SVO_NO_NEST
             const bool ent = false;
