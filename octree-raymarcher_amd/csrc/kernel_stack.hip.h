@@ -63,6 +63,15 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #define SVO_CREEP_LANES 8
 #endif
 // the step runs up to 1 + SVO_STEP_EXTRA times per pass of the outer loop while at least SVO_STEP_LANES lanes are marching
+// Block placement: a taken branch costs a shared SIMD about three vector instructions' time, a not-taken one about one
+// (scripts/microbench/valu_issue.hip) - rare blocks go out of line so that the common path falls through.
+#ifdef SVO_NO_EXPECT
+#define SVO_LIKELY(x) (x)
+#define SVO_UNLIKELY(x) (x)
+#else
+#define SVO_LIKELY(x) __builtin_expect(!!(x), 1)
+#define SVO_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
 #ifndef SVO_STEP_EXTRA
 #define SVO_STEP_EXTRA 3
 #endif
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                                                __ballot(mode == M_WORLD && creepn <= -SVO_CREEP_SERIOUS) != 0ull);
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
-        if (mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD) {     // runaway ray: give up, flag it
+        if (SVO_UNLIKELY(mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD)) {     // runaway ray: give up, flag it
             if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
             else store_miss(A.out, outk, SVO_ERR_FLAG);
             mode = M_DONE;
@@ -427,11 +436,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      The step repeats at once, without the refill / vote / block checks around it, while every live lane of the
         //      wave is marching and nothing else can be due: that is the state of the waves that carry a launch's longest
         //      rays after the tile cursors ran dry, alone on their SIMD and bound by their own instruction stream.
-        bool again;
         int pass = 0;
         // in the bulk: SVO_STEP_EXTRA more steps, decided once per pass of the outer loop (n_busy: before the chunk step)
         const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? SVO_STEP_EXTRA : 0;
-        do {
+        for (;;) {
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_STACK_TIMING
             n_fix += __ballot(!twig && ((fx == (float)ux) | (fy == (float)uy) | (fz == (float)uz))) != 0;
 #endif
-            if (!twig && ((fx == (float)ux) | (fy == (float)uy) | (fz == (float)uz))) {
+            if (SVO_UNLIKELY(!twig && ((fx == (float)ux) | (fy == (float)uy) | (fz == (float)uz)))) {
                 const int nmax = (1 << levels) - 1;
                 ux = ux > nmax ? nmax : ux; uy = uy > nmax ? nmax : uy; uz = uz > nmax ? nmax : uz;
                 ux -= (Blo.x + (float)ux * res > p.x) ? 1 : 0;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             int what = S_LEAVE;
             int low = 0;                                            // the located cell spans (low+1) lattice steps
             uint32_t payload = 0;                                   // node word (tree) / cell index (brick)
-            if (!leave) {
+            if (SVO_LIKELY(!leave)) {
                 if (!twig) {
                     // descend through the chunk's wide tree (wide_tree.hip.h: two reference levels per node) from the
                     // deepest cached wide level whose node is unchanged: wide level k is selected by the coordinate bits
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 const V3 E_lo = mk(Blo.x + (float)(ux & keepm) * res, Blo.y + (float)(uy & keepm) * res, Blo.z + (float)(uz & keepm) * res);
                 const float E_size = leave ? Bsize : res * (float)(low + 1);
                 const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
-                if (!leave) {
+                if (SVO_LIKELY(!leave)) {
                     t += e;
                     creepn = e < 2.0f * eps ? crept + 1 : 0;        // pinned on a lattice plane: see the creep block
                 } else if (twig) {                                  // back to the tree level that entered the brick
@@ -547,13 +555,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // hit blocks) cost a quarter of an iteration, even one ballot per step 2 %; the lanes that wait a step or two
         // longer for a refill or a vote cost less.  The per-lane runaway guard is settled after the loop, which ends
         // after 256 steps at the latest so that the outer loop's check sees a runaway ray.
-        if (pass < fixed_steps) { again = true; ++pass; }
-        else {
-            const unsigned long long marching = __ballot(mode == M_TREE || mode == M_TWIG);
-            again = !more && marching != 0ull && marching == __ballot(mode != M_DONE) && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull && pass < 256;
-            ++pass;
+        ++pass;
+        if (pass <= fixed_steps) continue;
+        if (more || pass >= 256) break;
+        const unsigned long long marching = __ballot(mode == M_TREE || mode == M_TWIG);
+        if (marching == 0ull || marching != __ballot(mode != M_DONE) || __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) != 0ull) break;
         }
-        } while (again);
         guard += pass - 1;
 
         // ---- creep block.  A ray that sits exactly on a lattice plane (p.a == lo.a of its cell) and moves towards the

@@ -16,16 +16,21 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { OP_FMA = 0, OP_ADDU = 1, OP_BFE = 2, OP_CMPSEL = 3, OP_MULCVT = 4, OP_PKMUL = 5, OP_PKADD = 6, N_OPS = 7 };
-static const char *op_name[N_OPS] = { "v_fma_f32", "v_add_u32", "v_bfe_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_mul_f32+v_cvt_i32_f32", "v_pk_mul_f32", "v_pk_add_f32" };
-static const int op_insts[N_OPS] = { 1, 1, 1, 2, 2, 1, 1 };     // VALU instructions per "op" below
+enum { OP_FMA = 0, OP_ADDU = 1, OP_BFE = 2, OP_CMPSEL = 3, OP_MULCVT = 4, OP_PKMUL = 5, OP_PKADD = 6, OP_FMA_BR_NT = 7, OP_FMA_BR_T = 8, OP_FMA_SALU = 9, OP_FMA_NOP = 10, N_OPS = 11 };
+static const char *op_name[N_OPS] = { "v_fma_f32", "v_add_u32", "v_bfe_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_mul_f32+v_cvt_i32_f32", "v_pk_mul_f32", "v_pk_add_f32",
+                                     "v_fma_f32 + s_cbranch_execz (not taken)", "v_fma_f32 + s_cbranch_execnz (taken, to the next instruction)",
+                                     "v_fma_f32 + s_and_b64", "v_fma_f32 + s_nop 1" };
+static const int op_insts[N_OPS] = { 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1 };     // VALU instructions per "op" below (the companions of the last four: compare with v_fma_f32 alone)
 
 constexpr int UNROLL = 8;       // independent accumulators
 constexpr int INNER = 16;       // ops per accumulator per loop trip (loop overhead: 2 SALU per 128+ VALU)
 
 template <int OP>
-__global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned long long *cycles, float *sink)
+__global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned long long *cycles, float *sink, int pattern)
 {
+    // which lanes execute the stream (EXEC during the timed loop): 0 all 64, 1 the low 32, 2 the even lanes, 3 the low 16,
+    // 4 lane 0 alone - does the SIMD skip a half (quarter) of a wave64 instruction whose lanes are all off?
+    const bool on = pattern == 0 ? true : pattern == 1 ? threadIdx.x < 32 : pattern == 2 ? (threadIdx.x & 1) == 0 : pattern == 3 ? threadIdx.x < 16 : threadIdx.x == 0;
     float a[UNROLL];
     unsigned u[UNROLL];
     typedef float float2v __attribute__((ext_vector_type(2)));
@@ -35,7 +40,9 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
     float2v pm; pm.x = 1.0000001f; pm.y = 0.9999999f;
     const float m = 1.0000001f, c = 1e-7f;
     __builtin_amdgcn_s_barrier();
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t0 = 0, t1 = 0;
+    if (on) {
+    t0 = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < trips; ++t) {
 #pragma unroll
         for (int k = 0; k < INNER; ++k) {
@@ -48,11 +55,16 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
                 if (OP == OP_MULCVT) asm volatile("v_mul_f32 %0, %0, %2\n\tv_cvt_i32_f32 %1, %0" : "+v"(a[i]), "=v"(u[i]) : "v"(m));
                 if (OP == OP_PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pk[i]) : "v"(pm));
                 if (OP == OP_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[i]) : "v"(pm));
+                if (OP == OP_FMA_BR_NT) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_cbranch_execz 1f\n1:" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (OP == OP_FMA_BR_T) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_cbranch_execnz 1f\n1:" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (OP == OP_FMA_SALU) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_and_b64 s[40:41], s[40:41], exec" : "+v"(a[i]) : "v"(m), "v"(c) : "s40", "s41", "scc");
+                if (OP == OP_FMA_NOP) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 1" : "+v"(a[i]) : "v"(m), "v"(c));
             }
         }
     }
     asm volatile("s_nop 0" ::: "memory");
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    t1 = __builtin_amdgcn_s_memtime();
+    }
     float s = 0.0f; unsigned q = 0;
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) { s += a[i] + pk[i].x + pk[i].y; q += u[i]; }
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(64) void k_issue(int trips, float seed, unsigned lo
 }
 
 template <int OP>
-static void run(int waves_per_simd, int ncu, double clock_ghz, bool last)
+static void run(int waves_per_simd, int ncu, double clock_ghz, bool last, int pattern = 0)
 {
     const int trips = 2000;
     const int blocks = ncu * 4 * waves_per_simd;               // 64-thread blocks: the dispatcher spreads them over the SIMDs
@@ -69,10 +81,10 @@ static void run(int waves_per_simd, int ncu, double clock_ghz, bool last)
     CHECK(hipMalloc(&d_cyc, blocks * sizeof(unsigned long long)));
     CHECK(hipMalloc(&d_sink, 4));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, 10, 1.0f, d_cyc, d_sink);    // warm
+    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, 10, 1.0f, d_cyc, d_sink, pattern);    // warm
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, trips, 1.0f, d_cyc, d_sink);
+    hipLaunchKernelGGL(k_issue<OP>, dim3(blocks), dim3(64), 0, 0, trips, 1.0f, d_cyc, d_sink, pattern);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -83,10 +95,11 @@ static void run(int waves_per_simd, int ncu, double clock_ghz, bool last)
     const double med = (double)cyc[blocks / 2], p10 = (double)cyc[blocks / 10], p90 = (double)cyc[blocks * 9 / 10];
     // wall-clock view: every SIMD issues insts * W instructions in ms
     const double wall_cyc_per_inst = (ms * 1e-3 * clock_ghz * 1e9) / (insts * waves_per_simd);
-    printf("    {\"op\": \"%s\", \"waves_per_simd\": %d, \"valu_insts_per_wave\": %.0f, \"wave_cycles_median\": %.0f, "
+    static const char *pat[] = { "all 64 lanes", "low 32 lanes", "even lanes", "low 16 lanes", "lane 0" };
+    printf("    {\"op\": \"%s\", \"exec\": \"%s\", \"waves_per_simd\": %d, \"valu_insts_per_wave\": %.0f, \"wave_cycles_median\": %.0f, "
            "\"wave_cycles_p10\": %.0f, \"wave_cycles_p90\": %.0f, \"cycles_per_inst_per_simd\": %.3f, "
            "\"launch_ms\": %.4f, \"cycles_per_inst_per_simd_from_wall_at_%.1fGHz\": %.3f}%s\n",
-           op_name[OP], waves_per_simd, insts, med, p10, p90, med / (insts * waves_per_simd), ms, clock_ghz, wall_cyc_per_inst, last ? "" : ",");
+           op_name[OP], pat[pattern], waves_per_simd, insts, med, p10, p90, med / (insts * waves_per_simd), ms, clock_ghz, wall_cyc_per_inst, last ? "" : ",");
     CHECK(hipFree(d_cyc)); CHECK(hipFree(d_sink));
 }
 
@@ -106,7 +119,22 @@ int main()
         run<OP_CMPSEL>(w, ncu, ghz, false);
         run<OP_MULCVT>(w, ncu, ghz, false);
         run<OP_PKMUL>(w, ncu, ghz, false);
-        run<OP_PKADD>(w, ncu, ghz, w == 8);
+        run<OP_PKADD>(w, ncu, ghz, false);
+    }
+    // EXEC patterns: a partly filled wave costs the SIMD what?
+    for (int w : { 1, 5 })
+        for (int pattern = 0; pattern < 5; ++pattern) {
+            run<OP_FMA>(w, ncu, ghz, false, pattern);
+            run<OP_PKMUL>(w, ncu, ghz, false, pattern);
+            run<OP_CMPSEL>(w, ncu, ghz, false, pattern);
+        }
+    // what a scalar companion costs next to a vector instruction: branch (not taken / taken), SALU, s_nop
+    for (int w : { 1, 2, 5, 8 }) {
+        run<OP_FMA>(w, ncu, ghz, false);
+        run<OP_FMA_BR_NT>(w, ncu, ghz, false);
+        run<OP_FMA_BR_T>(w, ncu, ghz, false);
+        run<OP_FMA_SALU>(w, ncu, ghz, false);
+        run<OP_FMA_NOP>(w, ncu, ghz, w == 8);
     }
     printf("  ]\n}\n");
     return 0;
