@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     V3 O = mk(0, 0, 0), Blo = mk(0, 0, 0);
     // (the box edge, 1/res and the step cap follow from mode and res: chunk edge / 4 voxels, A.cap_tree / A.cap_twig)
     float res = 1.0f, t = 0.0f;
-    int cnt = 0;                    // step counter of the level; in M_HIT: the brick cell that was hit (or SVO_CELL_NONE: a LEAF)
+    int cnt = 0;                    // steps LEFT of the level's cap (counts down: cap - the reference's loop counter); in M_HIT: the brick cell that was hit (or SVO_CELL_NONE: a LEAF)
     float tt_saved = 0.0f;
     int it_saved = 0;
     // chunk
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         wide_b = ch.wide_off << 8;                   // 64 entries of 4 bytes per wide node
                         twig_off = (uint32_t)ch.twig_off;
                         levels = (int)ch.levels;
-                        O = p; t = 0.0f; cnt = 0;
+                        O = p; t = 0.0f; cnt = A.cap_tree;
                         Blo = clo;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
                         mode = M_TREE;
@@ -444,11 +444,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
             const float Bsize = twig ? res * 4.0f : csize, inv_res = recip_pow2(res);
-            const int cap = twig ? A.cap_twig : A.cap_tree;
             const int crept = creepn < 0 ? -creepn : creepn;
             creepn = -crept;                                        // disarmed unless this step advances (see the creep block)
-            bool leave = cnt >= cap;
-            cnt += leave ? 0 : 1;
+            bool leave = cnt <= 0;                                  // the level's step cap (src/Traverse.cpp:54,79)
+            cnt -= 1;                                               // (a lane that leaves restores or resets cnt below)
             const V3 p = O + beta * t;
             leave |= !inside(p, Blo, Blo + Bsize);
             // lattice coordinates of p inside the box.  Brick: truncation, as the reference (:58).  Tree: the number
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             if (what == S_ENTER) {                                  // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
                 bmask = A.mask[twig_off + (payload & WIDE_PAYLOAD)];
                 tt_saved = t; it_saved = cnt;
-                O = p; t = 0.0f; cnt = 0;
+                O = p; t = 0.0f; cnt = A.cap_twig;
                 Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                 res = (res * (float)(low + 1)) * 0.25f;             // leafsize = node size / 4, exact
                 mode = M_TWIG;
@@ -586,19 +585,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_NO_NEST
             const bool ent = false;
 #else
-            const bool ent = mode == M_TWIG && cnt == 0 && t == 0.0f && creepn <= -4 * SVO_CREEP_SERIOUS;     // fresh in a brick after a long creep
+            const bool ent = mode == M_TWIG && cnt == A.cap_twig && t == 0.0f && creepn <= -4 * SVO_CREEP_SERIOUS;     // fresh in a brick after a long creep
 #endif
             const unsigned long long crm = __ballot(cr);
             if (eps_pow2 && (__ballot(ent) != 0ull || (crm != 0ull && (__ballot(cr && creepn >= SVO_CREEP_SERIOUS) != 0ull || __popcll(crm) >= SVO_CREEP_LANES)))) {
                 const bool twig = mode == M_TWIG && !ent;           // closed form inside a brick cell
                 const float Bsize = mode == M_TWIG ? res * 4.0f : csize, inv_res = recip_pow2(res);
-                const int cap = mode == M_TWIG ? A.cap_twig : A.cap_tree;
                 const float finite_max = __uint_as_float(0x7F7FFFFFu);
                 bool go = (cr || ent) && (fabsf(g.x) <= finite_max) && (fabsf(g.y) <= finite_max) && (fabsf(g.z) <= finite_max);
                 // the frame the steps are taken in: the lane's own, or (ent) the tree level that entered the brick
                 const V3 fO = ent ? alpha + beta * tw : O;
                 const float ft = ent ? tt_saved : t;
-                const int kmax = ent ? A.cap_tree - it_saved + 1 : min(cap - cnt, (int)(STEP_GUARD - guard));
+                const int kmax = ent ? it_saved + 1 : min(cnt, (int)(STEP_GUARD - guard));     // steps left under the caps
                 const V3 q0 = fO + beta * ft;                       // where the next reference step starts
                 V3 lo;
                 float fvx = 0.0f, fvy = 0.0f, fvz = 0.0f;            // brick: the cell's lattice coordinates as floats
@@ -687,7 +685,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #endif
                     if (sure) {
                         t = tt_saved + (float)K * eps;
-                        cnt = it_saved + (K - 1);
+                        cnt = it_saved - (K - 1);
                         guard += (uint32_t)K; creepn -= K;
                         O = fO;
                         Blo = clo;
@@ -699,7 +697,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     }
                 } else if (K > 0) {
                     t += (float)K * eps;                            // == K times t + (escape + EPS) with escape == -0
-                    cnt += K; guard += (uint32_t)K; creepn += K;
+                    cnt -= K; guard += (uint32_t)K; creepn += K;
 #ifdef SVO_STACK_TIMING
                     n_creep_steps += K;
 #endif

@@ -46,7 +46,12 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     vi = os.path.join(G, "prof_valu_issue.json")
     if os.path.exists(vi):
         runs = json.load(open(vi))["runs"]
-        five = [r for r in runs if r["waves_per_simd"] == 5]
+        # the seven plain instruction mixes with every lane on (the file also holds EXEC patterns and scalar companions)
+        plain = {}
+        for r in runs:
+            if r["waves_per_simd"] == 5 and r.get("exec", "all 64 lanes") == "all 64 lanes" and " + " not in r["op"]:
+                plain.setdefault(r["op"], r)
+        five = list(plain.values())
         # wall-clock cycles per instruction per SIMD at 5 waves/SIMD (the march kernel's occupancy), mean over the instruction mixes
         key = [k for k in five[0] if k.startswith("cycles_per_inst_per_simd_from_wall")][0]
         rec["valu_cycles_per_inst"] = round(sum(r[key] for r in five) / len(five), 3)
