@@ -593,8 +593,8 @@ static int fill_cameras(const svo_camera *cams, int nframes, TraceArgs &A)
 static int launch_frames(svo_world *w, const svo_trace_params *prm, TraceArgs &A, const char *who, hipStream_t s)
 {
     A.n = (int64_t)A.w * A.h;
-    A.tiles_per_row = (A.w + 7) / 8;
-    const int64_t tiles = (int64_t)A.tiles_per_row * ((A.h + 7) / 8);
+    A.tiles_per_row = (A.w + TILE_W - 1) / TILE_W;
+    const int64_t tiles = (int64_t)A.tiles_per_row * ((A.h + TILE_H - 1) / TILE_H);
     if (tiles * A.nframes > 0x3FFFFFFF || A.n * A.nframes > 0x7FFFFFFF) { set_error(std::string(who) + ": image too large"); return SVO_ERR_UNSUPPORTED; }
     A.ntiles = (int32_t)tiles;
     if (A.nframes == 1) return launch(w, prm, A, s);

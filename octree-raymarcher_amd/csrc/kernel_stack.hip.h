@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     int k = -1;
                     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
                     if (T.from_camera) {
-                        const int lx = tcol * 8 + (lane & 7);
-                        const int ly = trow * 8 + (lane >> 3);
+                        const int lx = tcol * TILE_W + (lane & (TILE_W - 1));
+                        const int ly = trow * TILE_H + lane / TILE_W;
                         ok = (lx < T.w) & (ly < T.h);
                         k = (tframe * T.h + ly) * T.w + lx;
                         int px = 0, py = 0;

@@ -48,6 +48,12 @@ static_assert(sizeof(DevWide) == 32, "wide chunk table entry is 32 bytes");
 // Launch slot (u64 words).  The stack kernel deals the image out as TILE_REGIONS screen regions, one per XCD (own L2),
 // each with its own cursor; a wave whose region is empty moves on to the next one.
 constexpr int TILE_REGIONS = 8;
+// a tile = the 64 rays a wave picks up at once: TILE_W x TILE_H pixels of the raster
+#ifndef SVO_TILE_W
+#define SVO_TILE_W 8
+#endif
+constexpr int TILE_W = SVO_TILE_W, TILE_H = 64 / TILE_W;
+static_assert(TILE_W * TILE_H == 64 && (TILE_W & (TILE_W - 1)) == 0, "a tile is one wave of rays");
 constexpr int WORK_CURSOR0 = 2;
 constexpr int WORK_SLOT_WORDS = 16;     // 128 B: slots do not share a cache line
 
