@@ -84,7 +84,7 @@ __device__ __forceinline__ float recip_pow2(float x) { return __uint_as_float(0x
 
 // World::index(World::index_float(p)) for a power-of-two chunk edge (src/World.cpp:288-293,323-332):
 // p / chunksize == p * inv (exact), and positive_mod() of a coordinate that lies within one grid
-// period of the grid's first chunk is a conditional add/subtract.
+// period of the grid's first chunk is a conditional add/subtract.  Only for p inside the world box.
 __device__ __forceinline__ int chunk_index_pow2(const TraceArgs &A, V3 p)
 {
     float qx = p.x * A.inv_chunksize, qy = p.y * A.inv_chunksize, qz = p.z * A.inv_chunksize;
@@ -92,9 +92,10 @@ __device__ __forceinline__ int chunk_index_pow2(const TraceArgs &A, V3 p)
     if (qy < 0.0f) qy -= 1.0f;
     if (qz < 0.0f) qz -= 1.0f;
     const int ix = (int)qx, iy = (int)qy, iz = (int)qz;
+    // p lies inside the world box (the caller's isInsideCube test, src/Traverse.cpp:145): wlo <= p <= whi with
+    // wlo = ccm * chunksize and whi = (ccm + dims) * chunksize exactly, so ccm - 1 <= i <= ccm + dims per axis (the - 1:
+    // index_float sends an exact negative multiple one chunk down) - within one grid period, no general modulo needed
     const int rx = ix - A.ccm[0], ry = iy - A.ccm[1], rz = iz - A.ccm[2];
-    const bool near = (rx >= -A.dimw) & (rx <= A.dimw) & (ry >= -A.dimh) & (ry <= A.dimh) & (rz >= -A.dimd) & (rz <= A.dimd);
-    if (!near) return pmod(iy, A.dimh) * A.dimw * A.dimd + pmod(iz, A.dimd) * A.dimw + pmod(ix, A.dimw);
     int mx = A.cbase[0] + rx, my = A.cbase[1] + ry, mz = A.cbase[2] + rz;
     mx -= (mx >= A.dimw) ? A.dimw : 0; mx += (mx < 0) ? A.dimw : 0;
     my -= (my >= A.dimh) ? A.dimh : 0; my += (my < 0) ? A.dimh : 0;
