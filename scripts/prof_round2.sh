@@ -4,7 +4,7 @@
 # by scripts/summarize_profiles.py r02.
 set -e
 R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/prof_*
+rm -rf $R/gpurun_out/prof_kt $R/gpurun_out/prof_kt_serial $R/gpurun_out/prof_pmc* $R/gpurun_out/prof_calib* $R/gpurun_out/prof_*.log $R/gpurun_out/prof_valu_issue.json
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-diagnostics"
 # the timed command of the round: 32-camera path, 4 frames per launch, 4 launches in flight / serialized
