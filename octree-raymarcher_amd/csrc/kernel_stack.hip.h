@@ -29,9 +29,12 @@
 //    ballot shows enough lanes waiting for them (or nothing else is runnable).
 //  * Creeping rays - pinned on a lattice plane, advancing by EPS alone for thousands of steps, alone or nested over a
 //    brick whose marches are bound to miss - are taken in closed form by a vote-gated block (same t, same counters).
-//  * The step runs up to four times per pass of the outer loop while >= 16 lanes are marching, and keeps repeating once
-//    the tile cursors are dry and every live lane is marching: the refill / vote / block checks around it are a quarter
-//    of an iteration, and a launch's last waves are alone on their SIMD, bound by their own instruction stream.
+//  * The step runs four times per pass of the outer loop while >= 8 lanes are marching (decided before the loop: nothing
+//    is voted on between the steps, the loop control is scalar), and keeps repeating once the tile cursors are dry and
+//    every live lane is marching: the refill / vote / block checks around it are a quarter of an iteration, and a
+//    launch's last waves are alone on their SIMD, bound by their own instruction stream.  Scalar instructions and
+//    branches cost a SIMD what vector instructions do (scripts/microbench/valu_issue.hip): the step avoids them
+//    where a select or an unconditional LDS read does the same.
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
 //    reference's own expressions instead of being held): 96 VGPRs, 5 waves per SIMD.
 //
