@@ -412,7 +412,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     // The descent cache (stk column, pux/puy/puz, valid) is keyed by chunk and cell, not by ray: a ray that
                     // enters the chunk this lane marched last - a shadow ray leaving its primary hit, the next pixel of the
                     // tile, a ray pinned on a chunk face - restarts below the deepest common level instead of at the root.
-                    if (ci_new != ci) valid = 0;
+                    // Another chunk: nothing of the cache holds.  The cached cell goes too: chunks may differ in depth
+                    // (src/Octree.h:56-76: an Ocroot carries its own), and a cell of a deeper chunk would make the next
+                    // descent compute a common prefix above this chunk's top level (keep < 0).
+                    if (ci_new != ci) { valid = 0; pux = 0; puy = 0; puz = 0; }
                     ci = ci_new;
                     const DevWide ch = A.wchunks[ci];
                     clo = ld3(ch.bmin);
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     const int nw = levels ? (levels + 1) >> 1 : 1;
                     const int hb = 32 - __clz((int)(diff | 1u));    // (diff == 0 reads as "bit 0 differs": keep = nw - 1 >= valid either way)
                     const int keep = nw - ((hb + 1) >> 1);
-                    int k = keep < valid ? keep : valid;
+                    int k;                                          // min(keep, valid), never below the top level (one v_med3_i32)
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(k) : "v"(keep), "v"(valid));
                     uint32_t wnode = stk[k][lane];                  // (row 0 holds node 0: no branch for k == 0)
                     int sh = 2 * (nw - 1 - k);                      // the two coordinate bits that select the entry
                     uint32_t word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));

@@ -505,3 +505,35 @@ def test_face_normal_mode(svo, oracle, worlds, kernel):
     svo.lib.svo_stream_synchronize(None)
     back = b.to_numpy(svo.HIT_DTYPE, flat.size)
     assert np.array_equal(back["flags"], flat["flags"]) and np.array_equal(back["normal"][hit.reshape(-1)], n)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_chunks_of_different_depths(svo, oracle, kernel):
+    """One world whose chunks have different depths (the reference's Ocroot carries its own depth, src/Octree.h:56-76, and
+    its LOD pass re-grows single chunks at another one): lanes of one wave march trees of 1, 3, 4 and 6 branch levels -
+    odd and even, i.e. with and without a padded top wide node - and cross from one into the other."""
+    depths = [3, 5, 6, 8]                                   # chunk i of the 2x1x2 grid
+    gen = {d: svo.World.generate(2, 1, 2, 128, d) for d in sorted(set(depths))}
+    chunks = [gen[d].chunk(i) for i, d in enumerate(depths)]
+    assert [int(c["depth"]) for c in chunks] == depths
+    W = svo.World.create(chunks, 2, 1, 2, 128)
+    O = oracle.OracleWorld.from_chunks(chunks, 2, 1, 2, 128, (0, 0, 0))
+    W.upload(0)
+    assert W.info.exact_geometry
+    lo = np.zeros(3); hi = np.array([256.0, 128.0, 256.0])
+    rng = np.random.default_rng(99)
+    o, d = random_rays(rng, 40000, lo, hi)
+    want = O.trace_rays(o, d, threads=8)
+    got = W.chunkmarch(o, d, kernel=_kid(svo, kernel))
+    hit = (want["flags"] & 1) != 0
+    assert hit.sum() > 2000 and len(set(want["chunk"][hit].tolist())) == 4          # every depth is hit
+    assert_gbuffer_equal(got, want, f"mixed depths rays/{kernel}")
+    cam = svo.default_camera(2, 2, 128, 320, 180)
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+    got = W.draw(cam, shadow=True, kernel=_kid(svo, kernel))
+    assert_gbuffer_equal(got, want, f"mixed depths frame/{kernel}")
+    o2, d2 = adversarial_rays(np.random.default_rng(5), 60000, lo, hi)
+    assert_gbuffer_equal(W.chunkmarch(o2, d2, kernel=_kid(svo, kernel)), O.trace_rays(o2, d2, threads=8), f"mixed depths adversarial/{kernel}")
+    W.destroy()
+    for g in gen.values():
+        g.destroy()
