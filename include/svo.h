@@ -131,7 +131,9 @@ typedef struct svo_camera {
 enum {                              /* svo_trace_params.kernel */
     SVO_KERNEL_AUTO    = 0,         /* fastest kernel valid for this world */
     SVO_KERNEL_LITERAL = 1,         /* one thread per ray, restart-from-root, any geometry */
-    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill */
+    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill: exact geometry, chunk depth <= 17
+                                       (chunks of one world may differ in depth), wide-tree pool below 4 GiB;
+                                       SVO_ERR_UNSUPPORTED otherwise (AUTO falls back to LITERAL) */
 };
 
 typedef struct svo_trace_params {

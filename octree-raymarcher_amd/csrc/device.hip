@@ -269,7 +269,8 @@ static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
 static bool wide_fits(const svo_world &w, int chunk)
 {
     const ChunkPools &c = w.chunks[(size_t)chunk];
-    return c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && c.tree.size() / 8 + 1 <= (uint64_t)WIDE_PAYLOAD_MASK;
+    // (a wide entry keeps its reference node's level in 4 bits: 0..15 branch levels, i.e. chunk depth <= 17)
+    return c.depth - TWIG_LEVELS <= 15u && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && c.tree.size() / 8 + 1 <= (uint64_t)WIDE_PAYLOAD_MASK;
 }
 
 // Wide trees of every chunk: a count pass into scratch sizes the pool (each chunk's slot = its wide nodes + 25 % + 16),
@@ -526,10 +527,10 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
     // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
     // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
-    const bool stack_ok = w->exact_geometry && w->max_levels <= 16 && w->wide_ok;
+    const bool stack_ok = w->exact_geometry && w->max_levels <= 15 && w->wide_ok;
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
-        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, depth <= 18 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 17 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }

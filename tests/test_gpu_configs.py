@@ -144,3 +144,32 @@ def test_c5_depth16_sparse(svo, oracle):
     assert hit.mean() > 0.5
     assert deep.sum() >= 0.25 * hit.sum(), f"only {deep.sum() / hit.sum():.3f} of the hits sit at level 14"
     W.destroy()
+
+
+@pytest.mark.parametrize("depth", [17, 18])
+def test_deepest_chunks(svo, oracle, depth):
+    """The stack kernel's wide entries keep the reference node's level in 4 bits: 15 branch levels (chunk depth 17) is
+    the deepest world it marches; at depth 18 SVO_KERNEL_STACK is refused and SVO_KERNEL_AUTO falls back to the literal
+    kernel.  Same sparse scene as configs[4], the refined band narrowed so that the pools stay small."""
+    scene = svo.c5_scene()
+    half = 0.5 if depth == 17 else 0.125
+    gen = dict(scene["generate"], refine_box=((64.3 - half, -1e9, -1e9), (64.3 + half, 1e9, 1e9)))
+    W = svo.World.generate(1, 1, 1, 128, depth, **gen)
+    assert W.info.max_chunk_depth == depth and W.info.exact_geometry == 1
+    chunk = W.chunk(0, copy=False)
+    assert len(node_levels(chunk["tree"])) - 2 == depth - 2          # nodes down to the deepest branch level
+    O = oracle.OracleWorld.from_chunks([chunk], 1, 1, 1, 128)
+    W.upload(0)
+    cam = scene["camera"](480, 270)
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=THREADS)
+    hit = (want["flags"] & 1) != 0
+    level = np.searchsorted(node_levels(chunk["tree"]), want["node"], side="right") - 1
+    assert hit.mean() > 0.5 and (hit & (level == depth - 2)).sum() > 500      # the deepest level is in the picture
+    assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL), want, f"depth {depth}/literal")
+    assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=svo.KERNEL_AUTO), want, f"depth {depth}/auto")
+    if depth <= 17:
+        assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=svo.KERNEL_STACK), want, f"depth {depth}/stack")
+    else:
+        with pytest.raises(svo.SvoError):
+            W.draw(cam, shadow=True, kernel=svo.KERNEL_STACK)
+    W.destroy()
