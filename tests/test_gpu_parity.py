@@ -537,3 +537,51 @@ def test_chunks_of_different_depths(svo, oracle, kernel):
     W.destroy()
     for g in gen.values():
         g.destroy()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("chunksize,depth,ccm", [(32, 6, (0, 0, 0)), (512, 7, (-1, 0, -2)), (2, 5, (3, -1, 0)), (1024, 9, (0, 0, 0))])
+def test_power_of_two_chunk_edges(svo, oracle, kernel, chunksize, depth, ccm):
+    """Chunk edges other than the reference's 128 (src/World.cpp: CHUNKSIZE): any power of two keeps the geometry exact, so
+    the stack kernel marches it - voxels of 1/16 world unit (edge 2, depth 5) up to 2 units (edge 1024, depth 9), world
+    boxes off the origin."""
+    W = svo.World.generate(2, 1, 2, chunksize, depth, chunkcoordmin=ccm)
+    assert W.info.exact_geometry == 1
+    chunks = chunks_of(W, 4)
+    O = oracle.OracleWorld.from_chunks(chunks, 2, 1, 2, chunksize, ccm)
+    W.upload(0)
+    lo = np.array(ccm, dtype=np.float64) * chunksize
+    hi = lo + np.array([2, 1, 2]) * chunksize
+    rng = np.random.default_rng(chunksize + depth)
+    for what, (o, d) in (("random", random_rays(rng, 30000, lo, hi)), ("adversarial", adversarial_rays(rng, 60000, lo, hi))):
+        want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+        got = W.chunkmarch(o, d, shadow=True, kernel=_kid(svo, kernel))
+        assert (want["flags"] & 1).sum() > 1000, what
+        assert_gbuffer_equal(got, want, f"chunk edge {chunksize} {what}/{kernel}")
+    W.destroy()
+
+
+def test_update_replaces_a_chunk_by_one_of_another_depth(svo, oracle):
+    """svo_world_update with a chunk re-grown at another depth (what the reference's LOD pass does to an Ocroot): the
+    pools, the chunk table, the chunk's wide tree and the kernel instantiation (LDS column height) follow - 4 branch
+    levels everywhere, then 7 and 1 in two of the chunks."""
+    W = svo.World.generate(2, 1, 2, 128, 6)
+    other = {d: svo.World.generate(2, 1, 2, 128, d) for d in (9, 3)}
+    chunks = chunks_of(W, 4)
+    W.upload(0)
+    cam = svo.default_camera(2, 2, 128, 320, 180)
+    rng = np.random.default_rng(3)
+    o, d = adversarial_rays(rng, 50000, np.zeros(3), np.array([256.0, 128.0, 256.0]))
+    for step, (i, depth) in enumerate(((None, None), (1, 9), (2, 3))):
+        if i is not None:
+            chunks[i] = other[depth].chunk(i)
+            W.update(i, chunks[i], tree_range=(0, chunks[i]["tree"].size), twig_range=(0, chunks[i]["twig"].size // 64), realloc=True)
+            assert W.info.max_chunk_depth == max(int(c["depth"]) for c in chunks)
+        O = oracle.OracleWorld.from_chunks(chunks, 2, 1, 2, 128, (0, 0, 0))
+        want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+        for kernel in KERNELS:
+            assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=_kid(svo, kernel)), want, f"after update {step}/{kernel}")
+            assert_gbuffer_equal(W.chunkmarch(o, d, kernel=_kid(svo, kernel)), O.trace_rays(o, d, threads=8), f"rays after update {step}/{kernel}")
+    W.destroy()
+    for g in other.values():
+        g.destroy()
