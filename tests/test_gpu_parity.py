@@ -585,3 +585,26 @@ def test_update_replaces_a_chunk_by_one_of_another_depth(svo, oracle):
     W.destroy()
     for g in other.values():
         g.destroy()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("band,stride", [(1, 2), (3, 3), (5, 2), (16, 3), (120, 1)])
+def test_band_heights_other_than_the_tile_height(svo, oracle, worlds, kernel, band, stride):
+    """svo_trace_rows with band heights that are not the stack kernel's 8-row tile height: tiles straddle bands (and the
+    padding below the image), every rank's rows still equal the whole frame's."""
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 203, 117)
+    full = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+    total = (117 + band - 1) // band
+    nb = (total + stride - 1) // stride
+    for rank in range(stride):
+        buf = svo.DeviceBuffer(nb * band * 203 * 32)
+        W.trace_rows(cam, svo.trace_params(shadow=True, kernel=_kid(svo, kernel)), rank, stride, nb, band, buf.ptr)
+        svo.lib.svo_stream_synchronize(None)
+        bands = buf.to_numpy(svo.HIT_DTYPE, nb * band * 203).reshape(nb, band, 203)
+        for k in range(nb):
+            y0 = (rank + stride * k) * band
+            rows = full[y0:y0 + band]
+            if rows.shape[0]:
+                assert_gbuffer_equal(bands[k, :rows.shape[0]], rows, f"band {band} rank {rank} #{k}/{kernel}")
+            assert np.all(bands[k, rows.shape[0]:]["flags"] == 0)
