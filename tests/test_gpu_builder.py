@@ -81,3 +81,18 @@ def test_device_builder_c3_world_and_speed(svo):
         assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
     print(f"\nC3 world generation: host threads {th:.2f} s (+ upload), device builder {td:.2f} s (resident: generate + upload)")
     H.destroy(); D.destroy()
+
+
+@pytest.mark.parametrize("chunksize,depth,ccm", [(32, 6, (0, 0, 0)), (512, 7, (-1, 0, -2)), (2, 5, (3, -1, 0))])
+def test_device_builder_other_chunk_edges(svo, oracle, chunksize, depth, ccm):
+    """Chunk edges other than the reference's 128: the device builder, the host builder and the oracle's World::init
+    produce the same pools."""
+    H = svo.World.generate(2, 1, 2, chunksize, depth, chunkcoordmin=ccm)
+    D = svo.World.generate(2, 1, 2, chunksize, depth, chunkcoordmin=ccm, build_device=0)
+    O = oracle.OracleWorld.generate(2, 1, 2, chunksize, depth, chunkcoordmin=ccm)
+    for i in range(4):
+        a, b, c = H.chunk(i, copy=False), D.chunk(i, copy=False), O.chunk(i)
+        assert a["position"] == b["position"] == tuple(c["position"]) and a["depth"] == b["depth"] == c["depth"]
+        assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["tree"], c["tree"]), f"chunk {i}: node words differ"
+        assert np.array_equal(a["twig"], b["twig"]) and np.array_equal(a["twig"], c["twig"]), f"chunk {i}: bricks differ"
+    H.destroy(); D.destroy()
