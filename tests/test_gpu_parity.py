@@ -508,11 +508,12 @@ def test_face_normal_mode(svo, oracle, worlds, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-def test_chunks_of_different_depths(svo, oracle, kernel):
+@pytest.mark.parametrize("depths", [[3, 5, 6, 8], [9, 2, 4, 7]], ids=["3-5-6-8", "9-2-4-7"])
+def test_chunks_of_different_depths(svo, oracle, kernel, depths):
     """One world whose chunks have different depths (the reference's Ocroot carries its own depth, src/Octree.h:56-76, and
     its LOD pass re-grows single chunks at another one): lanes of one wave march trees of 1, 3, 4 and 6 branch levels -
     odd and even, i.e. with and without a padded top wide node - and cross from one into the other."""
-    depths = [3, 5, 6, 8]                                   # chunk i of the 2x1x2 grid
+    # depths[i]: chunk i of the 2x1x2 grid (depth 2: the chunk is one brick or one terminal node)
     gen = {d: svo.World.generate(2, 1, 2, 128, d) for d in sorted(set(depths))}
     chunks = [gen[d].chunk(i) for i, d in enumerate(depths)]
     assert [int(c["depth"]) for c in chunks] == depths
@@ -526,7 +527,7 @@ def test_chunks_of_different_depths(svo, oracle, kernel):
     want = O.trace_rays(o, d, threads=8)
     got = W.chunkmarch(o, d, kernel=_kid(svo, kernel))
     hit = (want["flags"] & 1) != 0
-    assert hit.sum() > 2000 and len(set(want["chunk"][hit].tolist())) == 4          # every depth is hit
+    assert hit.sum() > 2000 and len(set(want["chunk"][hit].tolist())) >= 3          # (a depth-2 chunk may be empty air)
     assert_gbuffer_equal(got, want, f"mixed depths rays/{kernel}")
     cam = svo.default_camera(2, 2, 128, 320, 180)
     want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
