@@ -609,3 +609,23 @@ def test_band_heights_other_than_the_tile_height(svo, oracle, worlds, kernel, ba
             if rows.shape[0]:
                 assert_gbuffer_equal(bands[k, :rows.shape[0]], rows, f"band {band} rank {rank} #{k}/{kernel}")
             assert np.all(bands[k, rows.shape[0]:]["flags"] == 0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_frames_over_a_sub_rectangle(svo, worlds, kernel):
+    """svo_trace_frames with a window that is not the whole image (and not tile-aligned): every frame's raster equals the
+    same window of a single-frame trace."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    w, h = 171, 93
+    rect = (13, 7, 101, 53)
+    cams = [svo.make_camera((100.0 + 9.0 * f, 140.0 - 5.0 * f, -30.0 + 4.0 * f), (0.05 * f, -0.5, 0.8), (0.0, 1.0, 0.0), 50.0 + 3 * f, w, h)
+            for f in range(5)]
+    prm = svo.trace_params(shadow=True, kernel=_kid(svo, kernel))
+    n = rect[2] * rect[3]
+    allb = svo.DeviceBuffer(len(cams) * n * 32)
+    W.trace_frames(cams, prm, rect, allb.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    got = allb.to_numpy(svo.HIT_DTYPE, len(cams) * n).reshape(len(cams), rect[3], rect[2])
+    for f, c in enumerate(cams):
+        full = W.draw(c, shadow=True, kernel=_kid(svo, kernel))
+        assert got[f].tobytes() == np.ascontiguousarray(full[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]).tobytes(), f"frame {f}"
