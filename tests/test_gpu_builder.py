@@ -96,3 +96,35 @@ def test_device_builder_other_chunk_edges(svo, oracle, chunksize, depth, ccm):
         assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["tree"], c["tree"]), f"chunk {i}: node words differ"
         assert np.array_equal(a["twig"], b["twig"]) and np.array_equal(a["twig"], c["twig"]), f"chunk {i}: bricks differ"
     H.destroy(); D.destroy()
+
+
+def test_update_of_a_device_resident_world(svo, oracle):
+    """A world built on the device (bricks never copied to the host) takes svo_world_update like any other: the edited
+    chunk's pools come from the caller, the other chunk's bricks stay where the builder left them; then a host copy of
+    the untouched chunk is still what the oracle generated."""
+    import ctypes as C
+    from helpers import assert_gbuffer_equal, random_rays
+    O = oracle.OracleWorld.generate(2, 1, 1, 128, 7)
+    D = svo.World.generate(2, 1, 1, 128, 7, build_device=0)
+    rng = np.random.default_rng(5)
+    o, d = random_rays(rng, 20000, (0, 0, 0), (256, 128, 128))
+    prm = oracle.make_params(shadow=True)
+    assert_gbuffer_equal(D.chunkmarch(o, d, shadow=True), O.trace_rays(o, d, params=prm, threads=8), "before")
+    for kind, lo, hi, mat in (("build", (20, 60, 20), (70, 110, 50), 5), ("destroy", (0, 0, 0), (128, 45, 30), 0)):
+        dt, dw = oracle.Delta(), oracle.Delta()
+        root = C.byref(O.w.chunk[0])
+        if kind == "build":
+            oracle.lib.orc_build(root, oracle.vec3(lo), oracle.vec3(hi), mat, C.byref(dt), C.byref(dw))
+        else:
+            oracle.lib.orc_destroy(root, oracle.vec3(lo), oracle.vec3(hi), C.byref(dt), C.byref(dw))
+        c = O.chunk(0)
+        D.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right),
+                 realloc=bool(dt.realloc_ or dw.realloc_))
+        want = O.trace_rays(o, d, params=prm, threads=8)
+        for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+            assert_gbuffer_equal(D.chunkmarch(o, d, shadow=True, kernel=k), want, f"after {kind}/kernel {k}")
+    a, b = O.chunk(1), D.chunk(1, copy=False)                       # fetched from HBM now
+    assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
+    a, b = O.chunk(0), D.chunk(0, copy=False)
+    assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
+    D.destroy()
