@@ -53,3 +53,23 @@ def test_march_after_shift_matches_oracle(svo, oracle):
     for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
         assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"shifted/{k}")
     assert (want["flags"] & 1).sum() > 2000
+
+
+@pytest.mark.gpu
+def test_shift_of_a_device_resident_world(svo, oracle):
+    """svo_world_shift on a world whose pools were built on the device and never copied to the host: the slid-in chunks
+    replace their slots, the others keep their device-only bricks; march and (lazily fetched) pools match a fresh world."""
+    W = svo.World.generate(3, 1, 3, 128, 6, build_device=0)
+    for off in [(1, 0, 0), (0, 0, -1), (-1, 0, 0), (-1, 0, 0)]:
+        W.shift(off)
+    ccm = tuple(W.info.chunkcoordmin)
+    assert ccm == (-1, 0, -1)
+    O = oracle.OracleWorld.generate(3, 1, 3, 128, 6, chunkcoordmin=ccm)
+    lo = np.array(ccm, float) * 128
+    hi = lo + np.array([3, 1, 3]) * 128
+    o, d = random_rays(np.random.default_rng(9), 20000, lo, hi)
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"shifted resident/{k}")
+    F = svo.World.generate(3, 1, 3, 128, 6, chunkcoordmin=ccm)
+    worlds_equal(W, F, 9)
