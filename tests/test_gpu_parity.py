@@ -629,3 +629,14 @@ def test_frames_over_a_sub_rectangle(svo, worlds, kernel):
     for f, c in enumerate(cams):
         full = W.draw(c, shadow=True, kernel=_kid(svo, kernel))
         assert got[f].tobytes() == np.ascontiguousarray(full[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]).tobytes(), f"frame {f}"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_tiny_images_and_extreme_fields_of_view(svo, oracle, worlds, kernel):
+    """Images smaller than one 8x8 tile (down to one pixel) and fields of view of 1 and 170 degrees."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    for (w, h) in ((1, 1), (1, 7), (9, 1), (2, 2), (63, 65), (7, 9)):
+        for fov in (1.0, 60.0, 170.0):
+            cam = svo.make_camera((130.3, 150.0, -40.0), (0.1, -0.5, 0.85), (0.0, 1.0, 0.0), fov, w, h)
+            want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=4)
+            assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=_kid(svo, kernel)), want, f"{w}x{h} fov {fov}/{kernel}")
