@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -270,48 +271,82 @@ static bool wide_fits(const svo_world &w, int chunk)
 {
     const ChunkPools &c = w.chunks[(size_t)chunk];
     // (a wide entry keeps its reference node's level in 4 bits: 0..15 branch levels, i.e. chunk depth <= 17)
-    return c.depth - TWIG_LEVELS <= 15u && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && c.tree.size() / 8 + 1 <= (uint64_t)WIDE_PAYLOAD_MASK;
+    // and the builder scans one level's entries (64 per wide node) with 32-bit counts: < 2^31 entries per chunk
+    return c.depth - TWIG_LEVELS <= 15u && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && (c.tree.size() / 8 + 1) * 64 < (1ull << 31);
 }
 
 // Wide trees of every chunk: a count pass into scratch sizes the pool (each chunk's slot = its wide nodes + 25 % + 16),
 // the build pass writes them in place.  The node words must already be in the tree pool.
+static void drop_wide(svo_world &w)
+{
+    (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); w.d_wide = w.d_wref = nullptr;
+    w.wide_ok = false;
+    w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
+}
+static void drop_wide_scratch(svo_world &w)
+{
+    if (w.d_wscratch) { (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; }
+    w.wscratch_words = 0;
+}
+// test hook: SVO_TEST_FAIL_WIDE=1 makes the next wide-tree build fail as an allocation failure would
+static bool wide_fault_injected()
+{
+    const char *e = std::getenv("SVO_TEST_FAIL_WIDE");
+    return e && e[0] == '1';
+}
+
 int build_wide_all(svo_world &w, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     const size_t n = w.chunks.size();
-    w.wide_ok = true;
+    // wide_ok says "the wide pool is complete": false from here until the build pass has succeeded, so that a failure
+    // on the way (scratch or pool allocation, a malformed tree) leaves a world the literal kernel marches, never a
+    // stack kernel reading a null or half-written pool
+    drop_wide(w);
+    bool fits = true;
     uint64_t largest = 0;
-    for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree.size()); if (!wide_fits(w, (int)i)) w.wide_ok = false; }
-    (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); w.d_wide = w.d_wref = nullptr;
+    for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree.size()); if (!wide_fits(w, (int)i)) fits = false; }
     w.wtable.assign(n, DevWide()); w.wide_slot.assign(n, 0);
-    w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
-    if (!w.wide_ok) return SVO_OK;                                      // the literal kernel marches such a world
+    if (!fits) return SVO_OK;                                           // the literal kernel marches such a world
     int rc = reserve_wide_scratch(w, largest);
-    if (rc != SVO_OK) return rc;
+    if (rc == SVO_OK && wide_fault_injected()) { set_error("wide tree: injected allocation failure"); rc = SVO_ERR_OUT_OF_MEMORY; }
+    if (rc != SVO_OK) { drop_wide_scratch(w); return rc; }
     const uint64_t Bmax = largest / 8 + 1;
     uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
-    uint64_t cur = 0;
+    uint64_t cur = 0, used = 0;
     for (size_t i = 0; i < n; ++i) {
         uint64_t count = 0;
-        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) return rc;
+        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) { drop_wide_scratch(w); return rc; }
         const DevChunk &e = w.table[i];
         DevWide &v = w.wtable[i];
         v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
         v.levels = e.levels; v.wide_off = (uint32_t)cur; v._pad = 0; v.twig_off = e.twig_off;
-        w.wide_slot[i] = count + count / 4 + 16;
+        w.wide_slot[i] = count + count / 8 + 16;
         cur += w.wide_slot[i];
-        w.wide_nodes_used += count;
+        used += count;
     }
-    w.wide_pool_len = cur;
-    w.wide_pool_cap = cur + cur / 4 + 64;
-    if (w.wide_pool_cap * 64 >= (1ull << 30)) { w.wide_ok = false; return SVO_OK; }         // 32-bit byte offsets into the pool
-    if (hipMalloc((void **)&w.d_wide, w.wide_pool_cap * 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_wref, w.wide_pool_cap * 64 * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY; }
+    const uint64_t cap = cur + cur / 16 + 64;
+    if (cap * 64 >= (1ull << 30)) { drop_wide_scratch(w); return SVO_OK; }    // 32-bit byte offsets into the pool: literal kernel
+    if (hipMalloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_wref, cap * 64 * sizeof(uint32_t)) != hipSuccess) {
+        drop_wide(w); drop_wide_scratch(w);
+        set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY;
+    }
     for (size_t i = 0; i < n; ++i) {
         const DevWide &v = w.wtable[i];
-        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wref + (uint64_t)v.wide_off * 64, w.wide_slot[i], nullptr)) != SVO_OK) return rc;
+        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wref + (uint64_t)v.wide_off * 64, w.wide_slot[i], nullptr)) != SVO_OK) {
+            drop_wide(w); drop_wide_scratch(w); return rc;
+        }
     }
-    HIP_TRY(hipMemcpy(w.d_wchunks, w.wtable.data(), n * sizeof(DevWide), hipMemcpyHostToDevice));
+    if (hipMemcpy(w.d_wchunks, w.wtable.data(), n * sizeof(DevWide), hipMemcpyHostToDevice) != hipSuccess) {
+        drop_wide(w); drop_wide_scratch(w); set_error("wide tree: chunk table copy failed"); return SVO_ERR_HIP;
+    }
+    w.wide_pool_len = cur; w.wide_pool_cap = cap; w.wide_nodes_used = used;
+    w.wide_ok = true;
+    // the builder's scratch (fronts, flags, ranks and a throw-away tree of the largest chunk: ~1 GB at C3) is only needed
+    // here and by svo_world_update, which re-reserves what the edited chunk needs
+    (void)hipStreamSynchronize(s);
+    drop_wide_scratch(w);
     return SVO_OK;
 }
 
@@ -322,29 +357,33 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
     hipStream_t s = (hipStream_t)stream;
     if (!w.wide_ok || !wide_fits(w, chunk)) return build_wide_all(w, stream);
     const ChunkPools &c = w.chunks[(size_t)chunk];
-    uint64_t largest = 0;
-    for (const ChunkPools &k : w.chunks) largest = std::max<uint64_t>(largest, k.tree.size());
-    int rc = reserve_wide_scratch(w, largest);
-    if (rc != SVO_OK) return rc;
-    const uint64_t Bmax = largest / 8 + 1;
+    // any failure below leaves the chunk's old wide tree in the pool while tree[] has changed: the pool is dropped
+    // (wide_ok = false) and the literal kernel takes over until a full rebuild succeeds
+    int rc = reserve_wide_scratch(w, c.tree.size());
+    if (rc == SVO_OK && wide_fault_injected()) { set_error("wide tree: injected allocation failure"); rc = SVO_ERR_OUT_OF_MEMORY; }
+    if (rc != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
+    const uint64_t Bmax = c.tree.size() / 8 + 1;
     uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
     uint64_t count = 0;
-    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wref, c.tree.size() / 8 + 1, &count)) != SVO_OK) return rc;
+    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
     DevWide &v = w.wtable[(size_t)chunk];
     const DevChunk &e = w.table[(size_t)chunk];
     if (count > w.wide_slot[(size_t)chunk]) {
         const uint64_t want = count + count / 4 + 16;
-        if (w.wide_pool_len + want > w.wide_pool_cap) return build_wide_all(w, stream);
+        if (w.wide_pool_len + want > w.wide_pool_cap) { drop_wide_scratch(w); return build_wide_all(w, stream); }
         v.wide_off = (uint32_t)w.wide_pool_len;
         w.wide_slot[(size_t)chunk] = want;
         w.wide_pool_len += want;
     }
     v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
     v.levels = e.levels; v.twig_off = e.twig_off;
-    HIP_TRY(hipMemcpyAsync(w.d_wide + (uint64_t)v.wide_off * 64, tmp_wide, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w.d_wref + (uint64_t)v.wide_off * 64, tmp_wref, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(w.d_wchunks + chunk, &v, sizeof(DevWide), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (hipMemcpyAsync(w.d_wide + (uint64_t)v.wide_off * 64, tmp_wide, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(w.d_wref + (uint64_t)v.wide_off * 64, tmp_wref, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(w.d_wchunks + chunk, &v, sizeof(DevWide), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        drop_wide(w); drop_wide_scratch(w); set_error("wide tree: copy of the rebuilt chunk failed"); return SVO_ERR_HIP;
+    }
+    drop_wide_scratch(w);
     return SVO_OK;
 }
 
@@ -527,7 +566,8 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
     // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
     // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
-    const bool stack_ok = w->exact_geometry && w->max_levels <= 15 && w->wide_ok;
+    // (brick indices are 32-bit in the kernel: twig_off + payload)
+    const bool stack_ok = w->exact_geometry && w->max_levels <= 15 && w->wide_ok && w->twig_pool_cap < (1ull << 32);
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
         if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 17 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }

@@ -209,6 +209,43 @@ def test_world_update_after_edits(svo, oracle):
     W.destroy()
 
 
+def test_failed_wide_rebuild_falls_back_to_the_literal_kernel(svo, oracle, monkeypatch):
+    """a wide-tree rebuild that fails (allocation failure injected through SVO_TEST_FAIL_WIDE) must
+    not leave the world marked as having a wide pool: svo_world_update reports the error, AUTO then marches with the
+    literal kernel (and still matches the oracle over the EDITED tree), SVO_KERNEL_STACK is refused, and the next
+    successful update brings the stack kernel back."""
+    import ctypes as C
+    O = oracle.OracleWorld.generate(2, 1, 1, 128, 6)
+    W = svo.World.create([O.chunk(i) for i in range(2)], 2, 1, 1, 128)
+    W.upload(0)
+    rng = np.random.default_rng(17)
+    o, d = random_rays(rng, 6000, (0, 0, 0), (256, 128, 128))
+    assert W.info.wide_nodes > 0
+
+    def edit(lo, hi, mat):
+        dt, dw = oracle.Delta(), oracle.Delta()
+        oracle.lib.orc_build(C.byref(O.w.chunk[0]), oracle.vec3(lo), oracle.vec3(hi), mat, C.byref(dt), C.byref(dw))
+        c = O.chunk(0)
+        W.update(0, c, tree_range=(0, c["tree"].size), twig_range=(0, c["twig"].size // 64), realloc=True)
+
+    monkeypatch.setenv("SVO_TEST_FAIL_WIDE", "1")
+    with pytest.raises(svo.SvoError) as e:
+        edit((20, 60, 20), (50, 90, 50), 5)
+    assert e.value.code == -3
+    monkeypatch.delenv("SVO_TEST_FAIL_WIDE")
+    assert W.info.wide_nodes == 0 and W.info.wide_pool_bytes == 0
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_AUTO), want, "auto after failed rebuild")
+    with pytest.raises(svo.SvoError):
+        W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_STACK)
+    edit((100, 100, 100), (104, 104, 104), 5)                       # succeeds: full rebuild of the wide pool
+    assert W.info.wide_nodes > 0
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, "after recovery")
+    W.destroy()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("eps,caps,light", [
     (1.0 / 4096.0, (0, 0, 0), (1.0, -1.0, 0.0)),          # the GLSL twin's EPS
