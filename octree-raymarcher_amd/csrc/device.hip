@@ -108,6 +108,10 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, hi
     const int64_t tiles = (int64_t)A.ntiles * (A.nframes > 0 ? A.nframes : 1);
     const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, w->occupancy_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
+#ifdef SVO_RAW_HITS
+    const int64_t records = A.n * (int64_t)(A.from_camera ? A.nframes : 1);
+    hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((records + 255) / 256)), dim3(256), 0, s, A);
+#endif
     return SVO_OK;
 }
 

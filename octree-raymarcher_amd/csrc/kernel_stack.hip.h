@@ -46,6 +46,12 @@
 
 namespace svo {
 
+#ifdef SVO_RAW_HITS
+constexpr uint32_t SVO_RAW_IF = SVO_RAW_FLAG;
+#else
+constexpr uint32_t SVO_RAW_IF = 0u;
+#endif
+constexpr int CW_ESCAPE_PENDING = (int)0x80000000;    // bit of the lane's chunk-step counter: tw still lacks the escape out of the chunk just left
 enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 
 #ifndef SVO_VOTE_WORLD
@@ -53,6 +59,9 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
 #endif
 #ifndef SVO_VOTE_HIT
 #define SVO_VOTE_HIT 16          // primary hits waiting for their G-buffer record
+#endif
+#ifndef SVO_VOTE_HIT_RAW
+#define SVO_VOTE_HIT_RAW 4
 #endif
 #ifndef SVO_VOTE_BUSY
 #define SVO_VOTE_BUSY 24         // fewer marching lanes than this: serve the waiting ones regardless
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
+    unsigned n_wsteps = 0, n_lsteps = 0, n_hit_wait = 0, n_dead_wait = 0, n_wsteps_b = 0, n_lsteps_b = 0, n_world_wait = 0, n_twig_b = 0;   // step bodies executed, marching lanes summed over them; M_HIT / M_DONE lanes summed over them
 #endif
 
     const V3 wlo = ld3(A.worldmin), whi = ld3(A.worldmax);
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     // (the box edge, 1/res and the step cap follow from mode and res: chunk edge / 4 voxels, A.cap_tree / A.cap_twig)
     float res = 1.0f, t = 0.0f;
     int cnt = 0;                    // steps LEFT of the level's cap (counts down: cap - the reference's loop counter); in M_HIT: the brick cell that was hit (or SVO_CELL_NONE: a LEAF)
-    float tt_saved = 0.0f;
+    float tt_saved = 0.0f, t_miss = 0.0f;  // tree-level t at the brick's entry; ... after the brick march has missed
     int it_saved = 0;
     // chunk
     V3 clo = mk(0, 0, 0);
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
         if (SVO_UNLIKELY(mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD)) {     // runaway ray: give up, flag it
-            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
+            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | SVO_RAW_IF | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
             else store_miss(A.out, outk, SVO_ERR_FLAG);
             mode = M_DONE;
         }
@@ -402,6 +412,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         n_step += __ballot(mode == M_TREE || mode == M_TWIG) != 0;
 #endif
         if (run_world && mode == M_WORLD) {
+            if (cw < 0) {                               // left its chunk in the step: t += escape(chunk box) + EPS, src/Traverse.cpp:164-168
+                cw &= ~CW_ESCAPE_PENDING;
+                tw += escape(O, g, clo, clo + csize) + eps;
+            }
             bool miss = cw >= A.cap_chunk;
             if (!miss) {
                 cw++;
@@ -447,6 +461,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // in the bulk: SVO_STEP_EXTRA more steps, decided once per pass of the outer loop (n_busy: before the chunk step)
         const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? SVO_STEP_EXTRA : 0;
         for (;;) {
+#ifdef SVO_STACK_TIMING
+        { const int nm = __popcll(__ballot(mode == M_TREE || mode == M_TWIG)); n_wsteps += nm > 0; n_lsteps += nm; if (more) { n_wsteps_b += nm > 0; n_lsteps_b += nm; n_hit_wait += __popcll(__ballot(mode == M_HIT)); n_dead_wait += __popcll(__ballot(mode == M_DONE)); n_world_wait += __popcll(__ballot(mode == M_WORLD)); n_twig_b += __popcll(__ballot(mode == M_TWIG)); } }
+#endif
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
@@ -510,38 +527,41 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 }
             }
 
-            // ---- the one escape evaluation of the step: t += escape + EPS.  advance: out of the located cell from p;
-            //      leave: out of the level's own box from its origin (src/Traverse.cpp:104-105 brick, :164-168 chunk)
-            if (what <= S_ADVANCE) {
-                const V3 E_p = leave ? O : p;
-                // (leave: the level's own box as the cell at offset 0 - Blo + 0 * res == Blo up to the sign of a zero, which
-                //  the subtraction of p forgets; one select instead of a branch around the cell's corner)
-                const int keepm = leave ? 0 : ~low;
-                const V3 E_lo = mk(Blo.x + (float)(ux & keepm) * res, Blo.y + (float)(uy & keepm) * res, Blo.z + (float)(uz & keepm) * res);
-                const float E_size = leave ? Bsize : res * (float)(low + 1);
-                const float e = escape(E_p, g, E_lo, E_lo + E_size) + eps;
-                if (SVO_LIKELY(!leave)) {
+            // ---- the one escape evaluation of the step, out of the located cell from p (src/Traverse.cpp:89,104-105,67):
+            //      an EMPTY node or an empty brick cell advances by it; a TWIG node about to be entered remembers where the
+            //      tree level goes on if the brick march misses - t + (escape(p, node box) + EPS), :104-105, the same
+            //      expression with the same operands - so that leaving the brick later costs no evaluation of its own.
+            //      A lane that leaves its level evaluates nothing here: out of a brick it resumes the tree level at the
+            //      remembered parameter; out of the chunk (:164-168) it only raises the "escape pending" bit of cw, and the
+            //      chunk step, for which it has to wait anyway, advances tw from the tree frame's origin, which stays put.
+            if (what == S_ADVANCE || what == S_ENTER) {
+                const V3 E_lo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
+                const float E_size = res * (float)(low + 1);
+                const float e = escape(p, g, E_lo, E_lo + E_size) + eps;
+                if (what == S_ADVANCE) {
                     t += e;
                     creepn = e < 2.0f * eps ? crept + 1 : 0;        // pinned on a lattice plane: see the creep block
-                } else if (twig) {                                  // back to the tree level that entered the brick
-                    t = tt_saved + e;
+                } else {                                            // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
+                    bmask = A.mask[twig_off + (payload & WIDE_PAYLOAD)];
+                    tt_saved = t; t_miss = t + e; it_saved = cnt;
+                    O = p; t = 0.0f; cnt = A.cap_twig;
+                    Blo = E_lo;
+                    res = E_size * 0.25f;                           // leafsize = node size / 4, exact
+                    mode = M_TWIG;
+                }
+            }
+            if (leave) {
+                if (twig) {                                         // back to the tree level that entered the brick
+                    t = t_miss;
                     cnt = it_saved;
                     O = alpha + beta * tw;                          // the chunk march's p (src/Traverse.cpp:144,158)
                     Blo = clo;
                     res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
                     mode = M_TREE;
                 } else {                                            // out of the chunk
-                    tw += e;
+                    cw |= CW_ESCAPE_PENDING;
                     mode = M_WORLD;
                 }
-            }
-            if (what == S_ENTER) {                                  // twigmarch(p, b, node box, ...): a = p, t = 0 (:99,53)
-                bmask = A.mask[twig_off + (payload & WIDE_PAYLOAD)];
-                tt_saved = t; it_saved = cnt;
-                O = p; t = 0.0f; cnt = A.cap_twig;
-                Blo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
-                res = (res * (float)(low + 1)) * 0.25f;             // leafsize = node size / 4, exact
-                mode = M_TWIG;
             }
             if (what == S_HIT_LEAF) {
                 tw = tw + (t - eps);                                // src/Traverse.cpp:93,160
@@ -716,6 +736,49 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
         }
 
+#ifdef SVO_RAW_HITS
+        // ---- hits (experiment, see DESIGN.md "measured and not kept").  A primary hit writes a RAW record - t, the hit voxel's
+        //      box, the address of its wide-tree entry, the brick cell - and becomes its own shadow ray at once; material,
+        //      reference node index and normal are filled in by k_resolve_hits behind this kernel.
+        if (mode == M_HIT && outk < 0) {
+            store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED | SVO_RAW_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
+            mode = M_DONE;
+        }
+        const int n_hit_now = __popcll(__ballot(mode == M_HIT));
+        if (n_hit_now > 0 && (n_hit_now >= SVO_VOTE_HIT_RAW || n_busy < SVO_VOTE_BUSY) && mode == M_HIT) {
+#ifdef SVO_STACK_TIMING
+            n_hit_runs += 1;
+#endif
+            const int nw = levels ? (levels + 1) >> 1 : 1;
+            const uint32_t at = wide_b + ((((valid > 0 ? stk[valid][lane] : 0u) << 6) + wide_slot(pux, puy, puz, 2 * (nw - 1 - valid))) << 2);
+            const uint32_t hitc = (uint32_t)cnt;
+            V3 vlo;
+            float vsize;
+            if (hitc == SVO_CELL_NONE) {
+                const int low = (1 << (levels - plev)) - 1;
+                vlo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
+                vsize = res * (float)(low + 1);
+            } else {
+                vlo = mk(Blo.x + (float)(hitc & 3u) * res, Blo.y + (float)((hitc >> 2) & 3u) * res, Blo.z + (float)(hitc >> 4) * res);
+                vsize = res;
+            }
+            const bool face = A.normal_mode == SVO_NORMAL_FACE;
+            const uint32_t flags = SVO_HIT_FLAG | SVO_RAW_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u) | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
+            store_raw_hit(A.out, outk, tw, vlo, vsize, flags, (uint32_t)ci, at, hitc);
+            mode = M_DONE;
+            if (A.shadow) {
+                alpha = alpha + beta * (tw - eps); beta = sdir; g = sg;
+                outk |= (int)0x80000000;
+                tw = 0.0f; cw = 0; guard = 0; creepn = 0;
+                bool hit = true;
+                if (!inside(alpha, wlo, whi)) tw = enter(alpha, beta, wlo, whi, hit) + eps;
+                mode = hit ? M_WORLD : M_DONE;
+                rays_marched++;
+            }
+        }
+    }
+
+#else
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && outk < 0) {
@@ -760,19 +823,62 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
     }
 
+#endif
     unsigned total = rays_marched;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
     if (lane == 0 && total) atomicAdd(&A.work[1], (unsigned long long)total);
 #ifdef SVO_STACK_TIMING
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
-        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x] = c;
+        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
-        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 1] = e;
+        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 1] = e;
         uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = n_dbg;
-        reinterpret_cast<uint4 *>(A.counters)[3 * blockIdx.x + 2] = f;
+        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 2] = f;
+        uint4 h; h.x = n_wsteps; h.y = n_lsteps; h.z = n_hit_wait; h.w = n_dead_wait;
+        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 3] = h;
+        uint4 h2; h2.x = n_wsteps_b; h2.y = n_lsteps_b; h2.z = n_world_wait; h2.w = n_twig_b;
+        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 4] = h2;
     }
 #endif
+}
+
+// (experiment, -DSVO_RAW_HITS) second half of a stack-kernel launch: every record k_trace_stack left RAW gets its material,
+// reference node index and normal.  The ray is generated again by the same code that generated it for the march.
+__global__ __launch_bounds__(256) void k_resolve_hits(TraceArgs A)
+{
+    const int64_t total = A.n * (int64_t)(A.from_camera ? A.nframes : 1);
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    uint4 *rec = reinterpret_cast<uint4 *>(A.out) + 2 * k;
+    const uint4 b = rec[1];
+    const uint32_t flags = b.x >> 16;
+    if (!(flags & SVO_RAW_FLAG)) return;
+    const uint4 a = rec[0];
+    V3 o, d;
+    if (A.from_camera) {
+        const int frame = (int)(k / A.n);
+        const int64_t r = k - (int64_t)frame * A.n;
+        const int ly = (int)(r / A.w), lx = (int)(r - (int64_t)ly * A.w);
+        int px, py;
+        local_to_pixel(A, lx, ly, px, py);
+        camera_ray(A.cams[frame], A.imgw, A.imgh, px, py, o, d);
+    } else {
+        o = ld3(A.origins + 3 * k);
+        d = ld3(A.dirs + 3 * k);
+    }
+    const float tw = __uint_as_float(a.x);
+    const V3 vlo = mk(__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    const float vsize = __uint_as_float(b.w);
+    const uint32_t hitc = b.x & 0xFFFFu;
+    const uint32_t word = ld_node(A.wide, b.z), node = ld_node(A.wref, b.z);
+    uint32_t material;
+    if (hitc == SVO_CELL_NONE) material = word & 0xFFFFu;
+    else material = A.twig[(A.wchunks[b.y].twig_off + (unsigned long long)(word & WIDE_PAYLOAD)) * TWIG_WORDS + hitc];
+    const V3 point = o + d * (tw - A.eps);
+    const bool face = A.normal_mode == SVO_NORMAL_FACE;
+    const V3 n = face ? face_normal(point, vlo, vlo + vsize, d) : cube_normal_pow2(point, vlo, vsize, A.eps);
+    store_hit(A.out, k, tw, n, material, flags & ~SVO_RAW_FLAG, b.y, node, hitc);
 }
 
 } // namespace svo

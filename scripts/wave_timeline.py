@@ -15,14 +15,19 @@ if os.environ.get("SVO_PATH_CAM"):                      # camera k of bench.py's
     import bench
     cam = bench.camera_path(svo, "c3_1080p_depth12_4x1x4_shadow", 4, 4, 1920, 1080)[int(os.environ["SVO_PATH_CAM"])]
 nblk = 256 * 32
+cams = [cam] * F
+if os.environ.get("SVO_PATH_CAMS"):                     # F consecutive cameras of the path from this one on
+    import bench
+    path = bench.camera_path(svo, "c3_1080p_depth12_4x1x4_shadow", 4, 4, 1920, 1080)
+    cams = [path[(int(os.environ["SVO_PATH_CAMS"]) + i) % len(path)] for i in range(F)]
 out = svo.DeviceBuffer(F * 1920 * 1080 * 32)
 for rep in range(3):
-    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 12), np.uint32))
+    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 20), np.uint32))
     prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, counters_dev=cnt.ptr)
-    W.trace_frames([cam] * F, prm, (0, 0, 1920, 1080), out.ptr)
+    W.trace_frames(cams, prm, (0, 0, 1920, 1080), out.ptr)
     svo.lib.svo_stream_synchronize(None)
-    c8 = cnt.to_numpy(np.uint32, nblk * 12).reshape(nblk, 12); c = c8[:, :4]; e = c8[:, 4:8]; f = c8[:, 8:]
-e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; c = c[c[:, 2] > 0]
+    c8 = cnt.to_numpy(np.uint32, nblk * 20).reshape(nblk, 20); c = c8[:, :4]; e = c8[:, 4:8]; f = c8[:, 8:12]; h = c8[:, 12:20]
+e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; h = h[c[:, 2] > 0]; c = c[c[:, 2] > 0]
 t0 = c[:, 0].min()
 st = (c[:, 0] - t0).astype(np.int64) * 0.01      # us
 en = (c[:, 1] - t0).astype(np.int64) * 0.01
@@ -46,3 +51,10 @@ print("block runs per iteration: world %.3f hit %.3f refill-rounds %.3f tilegen 
 print("avg lanes per iteration: tree %.1f twig %.1f world %.1f" % (e[:, 2].astype(np.int64).sum() / its, (e[:, 3] & 0xFFFFF).astype(np.int64).sum() / its, (e[:, 3] >> 20).astype(np.int64).sum() / its))
 print("cycles per wave-iteration overall: %.0f" % (tot_wave_cycles / its))
 print("creep block: runs per iteration %.4f, rounds per run %.1f" % (f[:, 0].astype(np.int64).sum() / its, f[:, 2].astype(np.int64).sum() / max(1, f[:, 0].astype(np.int64).sum())))
+
+hs = h.astype(np.int64).sum(axis=0)
+print("step bodies executed %d (%.2f per iteration), marching lanes per step body %.2f of 64; wave cycles per step body %.0f" % (hs[0], hs[0] / its, hs[1] / max(1, hs[0]), tot_wave_cycles / max(1, hs[0])))
+b = max(1, hs[4])
+print("while tiles remain (bulk): %d step bodies (%.1f %% of all), per step body: marching %.2f (in a brick %.2f), waiting for the chunk step %.2f, for the hit vote %.2f, retired %.2f" % (
+    hs[4], 100.0 * hs[4] / max(1, hs[0]), hs[5] / b, hs[7] / b, hs[6] / b, hs[2] / b, hs[3] / b))
+print("lane-steps total %d" % hs[1])
