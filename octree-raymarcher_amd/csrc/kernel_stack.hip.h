@@ -43,6 +43,7 @@
 // multiplications by the exact reciprocal, which is bit-identical.
 #pragma once
 #include "march.hip.h"
+#include "step_asm.hip.h"
 
 namespace svo {
 
@@ -52,7 +53,7 @@ constexpr uint32_t SVO_RAW_IF = SVO_RAW_FLAG;
 constexpr uint32_t SVO_RAW_IF = 0u;
 #endif
 constexpr int CW_ESCAPE_PENDING = (int)0x80000000;    // bit of the lane's chunk-step counter: tw still lacks the escape out of the chunk just left
-enum : int { M_DONE = 0, M_WORLD = 1, M_TREE = 2, M_TWIG = 3, M_HIT = 4 };
+enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     // (step_asm.hip.h: marching = mode > 2)
 
 #ifndef SVO_VOTE_WORLD
 #define SVO_VOTE_WORLD 8         // lanes waiting for a chunk step that make the wave run it
@@ -292,6 +293,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     int pux = 0, puy = 0, puz = 0, valid = 0, plev = 0;
     // brick
     unsigned long long bmask = 0;
+#ifndef SVO_CXX_STEP
+    // step_asm.hip.h keeps the level's box edge and the chunk's wide-level count / tree-level pitch instead of deriving them per step
+    float bsize = 0.0f, res_tree = 1.0f;
+    int nw_chunk = 1;
+    const uint32_t lds_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)&stk[0][lane];
+    StepUniform SU;
+    SU.csize = csize; SU.eps = eps; SU.eps2 = 2.0f * eps; SU.cap_twig = A.cap_twig; SU.wide = A.wide; SU.mask = A.mask;
+#endif
     // creeping rays: |creepn| = consecutive advances of this ray by less than 2 EPS (kept across level changes: a ray pinned
     // on a chunk face creeps at every level); > 0 only while the cell located last is known to be empty (creep block armed)
     int creepn = 0;
@@ -441,6 +450,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         O = p; t = 0.0f; cnt = A.cap_tree;
                         Blo = clo;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
+#ifndef SVO_CXX_STEP
+                        bsize = csize; res_tree = res; nw_chunk = levels ? (levels + 1) >> 1 : 1;
+#endif
                         mode = M_TREE;
                     }
                 }
@@ -464,6 +476,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_STACK_TIMING
         { const int nm = __popcll(__ballot(mode == M_TREE || mode == M_TWIG)); n_wsteps += nm > 0; n_lsteps += nm; if (more) { n_wsteps_b += nm > 0; n_lsteps_b += nm; n_hit_wait += __popcll(__ballot(mode == M_HIT)); n_dead_wait += __popcll(__ballot(mode == M_DONE)); n_world_wait += __popcll(__ballot(mode == M_WORLD)); n_twig_b += __popcll(__ballot(mode == M_TWIG)); } }
 #endif
+#ifndef SVO_CXX_STEP
+        // (step_asm.hip.h) the steps of this pass in one statement: 1 + fixed_steps at first, single steps while the inner repeat lasts
+        const int nsteps = pass == 0 ? 1 + fixed_steps : 1;
+        march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
+                        beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps);
+        pass += nsteps - 1;
+#else
         if (mode == M_TREE || mode == M_TWIG) {
             enum : int { S_LEAVE = 0, S_ADVANCE = 1, S_ENTER = 2, S_HIT_LEAF = 3, S_HIT_CELL = 4, S_BAD = 5 };
             const bool twig = mode == M_TWIG;
@@ -576,6 +595,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 mode = M_HIT;
             }
         }
+#endif
 
         // Loop control is wave-uniform (scalar compare and branch).  In the bulk the number of extra steps was fixed before
         // the loop: nothing is looked at between them - the checks around the step (refill, three votes, guard, creep vote,
@@ -718,6 +738,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         O = fO;
                         Blo = clo;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
+#ifndef SVO_CXX_STEP
+                        bsize = csize;
+#endif
                         mode = M_TREE;
 #ifdef SVO_STACK_TIMING
                         n_creep_steps += K;
