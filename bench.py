@@ -482,6 +482,52 @@ def run(args):
             "all": [round(v) for v in per_cam],
             "how": f"each of the {P} path cameras alone: one launch of {G} frames of that camera, back to back on one stream"}
 
+    # ---- single-frame latency (N=1): the reference's caller issues ONE World::draw per displayed frame (src/Main.cpp:190-222).
+    # One svo_trace per frame, strictly serialized, over the camera path; plain, and with the tiles handed out longest-first
+    # by the previous frame's per-tile step maxima (svo_trace_params.tile_cost_dev -> svo_tile_order -> tile_order_dev).
+    # The ordered figure includes the sort.  Records must be byte-identical either way.
+    single = None
+    if not multi and not share and args.kernel != "literal" and world.info.wide_nodes > 0:
+        st0 = streams[0]
+        ntl = ((iw + 7) // 8) * ((ih + 7) // 8)
+        cost = torch.zeros(ntl * 2, dtype=torch.int32, device=dev)
+        order = torch.zeros(ntl, dtype=torch.int32, device=dev)
+        prm1 = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_STACK)                 # tiles_per_wave 0: as many waves as the device keeps resident
+        prm1o = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_STACK, tile_cost_dev=cost.data_ptr(), tile_order_dev=order.data_ptr())
+        prm1c = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_STACK, tile_cost_dev=cost.data_ptr())
+        ob = bufs[0][0]
+
+        def lap(cams, ordered):
+            ms = []
+            with torch.cuda.stream(st0):
+                world.trace(cams[-1], prm1c if ordered else prm1, (0, 0, iw, ih), ob.data_ptr(), st0.cuda_stream)      # primes caches / the cost record
+                for c in cams:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(st0)
+                    if ordered:
+                        world.tile_order(cost.data_ptr(), order.data_ptr(), ntl, st0.cuda_stream)
+                        world.trace(c, prm1o, (0, 0, iw, ih), ob.data_ptr(), st0.cuda_stream)
+                    else:
+                        world.trace(c, prm1, (0, 0, iw, ih), ob.data_ptr(), st0.cuda_stream)
+                    b.record(st0)
+                    ms.append((a, b))
+            st0.synchronize()
+            return [a.elapsed_time(b) for a, b in ms]
+
+        plain_path, ord_path = lap(path, False), lap(path, True)
+        ord_frame = ob.clone()
+        lap(path[-1:], False)
+        same = bool(torch.equal(ord_frame, ob))
+        plain0, ord0 = lap([path[0]] * 8, False), lap([path[0]] * 8, True)
+        single = {
+            "how": "one svo_trace per frame, serialized on one stream, every camera of the path in turn (mean) and the SURVEY camera repeated; "
+                   "ordered = tiles handed out longest-first by the previous frame's tile costs, svo_tile_order's device sort included",
+            "plain_ms": {"mean": round(statistics.mean(plain_path), 4), "max": round(max(plain_path), 4), "survey_camera": round(statistics.median(plain0), 4)},
+            "ordered_ms": {"mean": round(statistics.mean(ord_path), 4), "max": round(max(ord_path), 4), "survey_camera": round(statistics.median(ord0), 4)},
+            "records_identical": same}
+        if not same:
+            raise SystemExit("bench.py: tile ordering changed the G-buffer - refusing to report")
+
     # ---- roofline leg (N=1): the kernel's own launch duration.  With launches in flight the per-launch time above
     # measures co-scheduling (S launches share the SIMDs), so the dominant kernel - one launch of G consecutive path
     # frames, as in the timed region - is also timed back-to-back on ONE stream with HIP events on that stream;
@@ -550,6 +596,8 @@ def run(args):
                 "world_generate_s": round(t_gen, 2), "world_generate": "on the rank's GPU, pools left in HBM", "world_generate_threads": gen_threads, "world_upload_s": round(t_up, 3),
             },
         }
+        if single:
+            result["single_frame_ms"] = single
         if diag:
             result["diagnostics"] = diag
         if not multi and not args.emulate_share:

@@ -57,7 +57,8 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 2           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record */
+#define SVO_ABI_VERSION 3           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record
+                                       3: svo_trace_params.tile_cost_dev / tile_order_dev, svo_tile_order */
 
 typedef enum svo_status {
     SVO_OK                 =  0,
@@ -131,7 +132,7 @@ typedef struct svo_camera {
 enum {                              /* svo_trace_params.kernel */
     SVO_KERNEL_AUTO    = 0,         /* fastest kernel valid for this world */
     SVO_KERNEL_LITERAL = 1,         /* one thread per ray, restart-from-root, any geometry */
-    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill: exact geometry, chunk depth <= 17
+    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill: exact geometry, chunk depth <= 24
                                        (chunks of one world may differ in depth), wide-tree pool below 4 GiB;
                                        SVO_ERR_UNSUPPORTED otherwise (AUTO falls back to LITERAL) */
 };
@@ -158,6 +159,16 @@ typedef struct svo_trace_params {
                                        on ties; signed like that component, against the ray if it is exactly 0) - the face the
                                        ray entered through, defined for every hit; such records carry SVO_FACE_NORMAL */
     int32_t  _reserved;
+    /* Frame-to-frame tile scheduling for the shortest SINGLE frame (the reference's caller issues one World::draw per
+     * displayed frame, src/Main.cpp:190-222).  A frame takes as long as its bulk or its longest ray, whichever is longer;
+     * handing the tiles out longest-first starts the long rays at once.  SVO_KERNEL_STACK only; both optional:
+     *   tile_cost_dev   [nframes][ntiles][2] u32, written: the largest step count of a primary ray of the 8x8-pixel tile and
+     *                   of a shadow ray of it (ntiles = ceil(w/8) * ceil(h/8) of the traced raster, row-major);
+     *   tile_order_dev  [ntiles] u32, read: the order in which every frame's tiles are handed out (a permutation of
+     *                   0..ntiles-1, e.g. svo_tile_order of the previous frame's cost: temporal coherence makes it a good
+     *                   predictor).  The records written are the same with any order. */
+    uint32_t       *tile_cost_dev;
+    const uint32_t *tile_order_dev;
 } svo_trace_params;
 enum { SVO_NORMAL_CUBE = 0, SVO_NORMAL_FACE = 1 };
 
@@ -278,6 +289,10 @@ int svo_trace_rows_frames(svo_world *, const svo_camera *cams, int nframes, cons
 /* chunkmarch over an explicit list: origins_dev/dirs_dev are [n][3] float on the device. */
 int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev, int64_t n,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);
+
+/* order_dev[0..ntiles) = the tile indices sorted by descending cost[i][0] + cost[i][1] (a stable device sort; cost_dev as
+ * svo_trace_params.tile_cost_dev of ONE frame wrote it).  Asynchronous on `stream`. */
+int svo_tile_order(svo_world *, const uint32_t *cost_dev, uint32_t *order_dev, int ntiles, void *stream);
 
 /* ---- packed G-buffer (8 bytes / pixel) for the multi-GPU gather ------------------------------------------
  * { float t; uint32 w } with w = material (bits 0-15) | flags & 0xFF (bits 16-23) | normal code (bits 24-30) |

@@ -82,7 +82,8 @@ class TraceParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_chunk_steps", C.c_int32), ("max_tree_steps", C.c_int32),
                 ("max_twig_steps", C.c_int32), ("shadow", C.c_int32), ("light_dir", C.c_float * 3),
                 ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p),
-                ("normal_mode", C.c_int32), ("_reserved", C.c_int32)]
+                ("normal_mode", C.c_int32), ("_reserved", C.c_int32),
+                ("tile_cost_dev", C.c_void_p), ("tile_order_dev", C.c_void_p)]
 
 
 class Material(C.Structure):
@@ -126,7 +127,7 @@ ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
     "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_packed", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
-    "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
+    "svo_tile_order", "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
 ]
@@ -159,6 +160,7 @@ lib.svo_trace.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int
 lib.svo_trace_rows.argtypes = [_P, C.POINTER(Camera), C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
 lib.svo_trace_frames.argtypes = [_P, C.POINTER(Camera), C.c_int, C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
 lib.svo_trace_rows_frames.argtypes = [_P, C.POINTER(Camera), C.c_int, C.POINTER(TraceParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]
+lib.svo_tile_order.argtypes = [_P, _P, _P, C.c_int, _P]
 lib.svo_trace_rays.argtypes = [_P, _P, _P, C.c_int64, C.POINTER(TraceParams), _P, _P]
 lib.svo_trace_last_ray_count.argtypes = [_P, _P, C.POINTER(C.c_uint64)]
 lib.svo_device_count.restype = C.c_int
@@ -255,7 +257,8 @@ def c5_scene() -> dict:
 
 
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
-                 caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0, normal_mode: int = 0) -> TraceParams:
+                 caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0, normal_mode: int = 0,
+                 tile_cost_dev: Optional[int] = None, tile_order_dev: Optional[int] = None) -> TraceParams:
     p = TraceParams()
     p.normal_mode = normal_mode
     p.eps = eps
@@ -265,6 +268,8 @@ def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0
     p.kernel = kernel
     p.counters_dev = counters_dev
     p.tiles_per_wave = tiles_per_wave
+    p.tile_cost_dev = tile_cost_dev
+    p.tile_order_dev = tile_order_dev
     return p
 
 
@@ -447,6 +452,10 @@ class World:
 
     def trace_rays(self, origins_ptr: int, dirs_ptr: int, n: int, params: TraceParams, out_ptr: int, stream: int = 0):
         _check(lib.svo_trace_rays(self._h, origins_ptr, dirs_ptr, n, C.byref(params), out_ptr, stream), "svo_trace_rays")
+
+    def tile_order(self, cost_ptr: int, order_ptr: int, ntiles: int, stream: int = 0):
+        """svo_tile_order: tile indices by descending cost (of one frame) into order_ptr."""
+        _check(lib.svo_tile_order(self._h, cost_ptr, order_ptr, ntiles, stream), "svo_tile_order")
 
     def last_ray_count(self, stream: int = 0) -> int:
         n = C.c_uint64()

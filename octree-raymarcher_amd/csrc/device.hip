@@ -63,6 +63,16 @@ __global__ __launch_bounds__(256) void k_brick_masks(const uint16_t *twig, uint6
     reinterpret_cast<uint8_t *>(mask + first)[i] = (uint8_t)bits;
 }
 
+// svo_tile_order: key = primary + shadow step maxima of the tile (saturating), value = the tile's index
+__global__ __launch_bounds__(256) void k_tile_keys(const uint32_t *cost, uint32_t *keys, uint32_t *idx, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = cost[2 * i], b = cost[2 * i + 1];
+    keys[i] = a + b < a ? 0xFFFFFFFFu : a + b;
+    idx[i] = (uint32_t)i;
+}
+
 static int launch_masks(svo_world &w, uint64_t first, uint64_t count, hipStream_t s)
 {
     if (!count) return SVO_OK;
@@ -79,12 +89,13 @@ int release_device(svo_world &w)
         (void)hipSetDevice(w.device);
         (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
         (void)hipFree(w.d_mask); (void)hipFree(w.d_work);
-        (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch);
+        (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
         for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
     }
     w.work_event.clear();
     w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_work = nullptr;
     w.d_wide = nullptr; w.d_wref = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
+    w.d_sort = nullptr; w.sort_bytes = 0;
     w.device = -1;
     w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear(); w.wtable.clear(); w.wide_slot.clear();
     w.tree_pool_len = w.twig_pool_len = w.tree_pool_cap = w.twig_pool_cap = 0;
@@ -274,9 +285,9 @@ static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
 static bool wide_fits(const svo_world &w, int chunk)
 {
     const ChunkPools &c = w.chunks[(size_t)chunk];
-    // (a wide entry keeps its reference node's level in 4 bits: 0..15 branch levels, i.e. chunk depth <= 17)
+    // (a wide entry keeps its reference node's level in 5 bits; WIDE_MAX_LEVELS branch levels, i.e. chunk depth <= 24, are marched)
     // and the builder scans one level's entries (64 per wide node) with 32-bit counts: < 2^31 entries per chunk
-    return c.depth - TWIG_LEVELS <= 15u && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && (c.tree.size() / 8 + 1) * 64 < (1ull << 31);
+    return c.depth - TWIG_LEVELS <= WIDE_MAX_LEVELS && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && (c.tree.size() / 8 + 1) * 64 < (1ull << 31);
 }
 
 // Wide trees of every chunk: a count pass into scratch sizes the pool (each chunk's slot = its wide nodes + 25 % + 16),
@@ -561,6 +572,8 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     const float inv = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
     A.sdir[0] = nx * inv; A.sdir[1] = ny * inv; A.sdir[2] = nz * inv;
     A.counters = prm ? prm->counters_dev : nullptr;
+    A.tile_cost = prm ? prm->tile_cost_dev : nullptr;
+    A.tile_order = prm ? prm->tile_order_dev : nullptr;
     A.work = w->d_work;                 // the launch picks its slot
     return SVO_OK;
 }
@@ -571,10 +584,10 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
     // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
     // (brick indices are 32-bit in the kernel: twig_off + payload)
-    const bool stack_ok = w->exact_geometry && w->max_levels <= 15 && w->wide_ok && w->twig_pool_cap < (1ull << 32);
+    const bool stack_ok = w->exact_geometry && w->max_levels <= (int)WIDE_MAX_LEVELS && w->wide_ok && w->twig_pool_cap < (1ull << 32);
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
-        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 17 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 24 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }
@@ -603,11 +616,13 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
         hipLaunchKernelGGL(k_trace_literal, dim3((unsigned)blocks), dim3(256), 0, s, A);
     } else {
         if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
+        if (A.tile_cost) HIP_TRY(hipMemsetAsync(A.tile_cost, 0, (size_t)A.ntiles * (size_t)(A.from_camera ? A.nframes : 1) * 2 * sizeof(uint32_t), s));
         int rc;
         const int tpw = prm ? prm->tiles_per_wave : 0;
         if (w->max_levels <= 6) rc = launch_stack<6>(w, A, tpw, s);
         else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, tpw, s);
-        else rc = launch_stack<16>(w, A, tpw, s);
+        else if (w->max_levels <= 16) rc = launch_stack<16>(w, A, tpw, s);
+        else rc = launch_stack<22>(w, A, tpw, s);
         if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());
@@ -715,6 +730,31 @@ int svo_trace_rays(svo_world *w, const float *origins_dev, const float *dirs_dev
     A.ntiles = (int32_t)tiles;
     A.out = out_dev;
     return launch(w, prm, A, (hipStream_t)stream);
+}
+
+int svo_tile_order(svo_world *w, const uint32_t *cost_dev, uint32_t *order_dev, int ntiles, void *stream)
+{
+    if (!w || !cost_dev || !order_dev || ntiles < 0) return SVO_ERR_INVALID_ARG;
+    if (w->device < 0) return SVO_ERR_NOT_UPLOADED;
+    if (ntiles == 0) return SVO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(w->device));
+    // scratch of the sort: keys in / out, indices in, and hipcub's own (cached in the handle, grown on demand)
+    size_t cub_bytes = 0;
+    uint32_t *nul = nullptr;
+    if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub_bytes, nul, nul, nul, nul, ntiles, 0, 32, s) != hipSuccess) return SVO_ERR_HIP;
+    const size_t need = (size_t)ntiles * 3 * sizeof(uint32_t) + cub_bytes + 256;
+    if (need > w->sort_bytes) {
+        if (w->d_sort) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(w->d_sort); w->d_sort = nullptr; w->sort_bytes = 0; }
+        if (hipMalloc(&w->d_sort, need) != hipSuccess) { set_error("svo_tile_order: hipMalloc failed"); return SVO_ERR_OUT_OF_MEMORY; }
+        w->sort_bytes = need;
+    }
+    uint32_t *keys = static_cast<uint32_t *>(w->d_sort), *keys_out = keys + ntiles, *idx = keys_out + ntiles;
+    void *tmp = reinterpret_cast<char *>(idx + ntiles) + ((256 - ((size_t)ntiles * 12) % 256) % 256);
+    hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, cost_dev, keys, idx, ntiles);
+    HIP_TRY(hipGetLastError());
+    if (hipcub::DeviceRadixSort::SortPairsDescending(tmp, cub_bytes, keys, keys_out, idx, order_dev, ntiles, 0, 32, s) != hipSuccess) { set_error("svo_tile_order: sort failed"); return SVO_ERR_HIP; }
+    return SVO_OK;
 }
 
 int svo_trace_last_ray_count(svo_world *w, void *stream, uint64_t *rays)

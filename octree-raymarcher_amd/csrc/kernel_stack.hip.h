@@ -152,7 +152,7 @@ __device__ __forceinline__ uint32_t ld_node(const uint32_t *pool, uint32_t boff)
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pool) + (size_t)boff);
 }
 // entry of a wide node (wide_tree.hip.h) for the cell (ux, uy, uz): its two coordinate bits at `sh` per axis, x lowest
-constexpr uint32_t WIDE_PAYLOAD = (1u << 26) - 1u;
+constexpr uint32_t WIDE_PAYLOAD = (1u << 25) - 1u;
 __device__ __forceinline__ uint32_t wide_slot(int ux, int uy, int uz, int sh)
 {
     const uint32_t bx = __builtin_amdgcn_ubfe((uint32_t)ux, (uint32_t)sh, 2u);
@@ -227,6 +227,24 @@ __device__ SVO_NEST_INLINE float brick_layer_first_touch(int k, V3 a, V3 b, V3 g
         }
     }
     return clean ? first * (1.0f - 0x1p-18f) : -1.0f;                  // the slab parameters carry a few ulps of their own
+}
+
+// svo_trace_params.tile_cost_dev: the step count of a ray that ends (or turns into its shadow ray) is folded into its tile's
+// record - [frame][tile][primary | shadow] maxima, what svo_tile_order sorts the next frame's tiles by.  Rare blocks only.
+__device__ __forceinline__ void note_tile_cost(int outk, uint32_t steps)
+{
+    const TraceArgs T = args_reloaded();
+    if (!T.tile_cost) return;
+    const int k = outk & 0x7FFFFFFF;
+    int tile, frame = 0;
+    if (T.from_camera) {
+        const int per = T.w * T.h;
+        frame = k / per;
+        const int r = k - frame * per;
+        const int ly = r / T.w, lx = r - ly * T.w;
+        tile = (ly / TILE_H) * T.tiles_per_row + lx / TILE_W;
+    } else tile = k >> 6;
+    atomicMax(&T.tile_cost[((size_t)frame * (size_t)T.ntiles + (size_t)tile) * 2 + (outk < 0 ? 1 : 0)], steps);
 }
 
 template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
@@ -311,6 +329,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         while (more && __popcll(dead) >= REFILL) {
             if (tile_next >= 64) {
                 int t32 = -1, tcol = 0, trow = 0, tframe = 0;   // raster index of the tile, its column and row, its frame
+                const uint32_t *order = args_reloaded().tile_order;
+                if (order) {                                    // caller's order (longest tiles first): one cursor, frame after frame
+                    regions_left = 0;
+                    unsigned long long tix = 0;
+                    if (lane == 0) tix = atomicAdd(&A.work[WORK_CURSOR0], 1ull);
+                    int t = __builtin_amdgcn_readfirstlane((int)tix);
+                    if (t < A.ntiles * A.nframes) {
+                        tframe = t / A.ntiles; t -= tframe * A.ntiles;
+                        t32 = (int)order[t];
+                        trow = t32 / tr_cols; tcol = t32 - trow * tr_cols;
+                    }
+                }
                 while (regions_left > 0) {
                     const int span = reg_q + (region < reg_rem ? 1 : 0);                    // columns (rows) of this region
                     const int first = region * reg_q + (region < reg_rem ? region : reg_rem);
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
             if (miss) {
                 if (outk >= 0) store_miss(A.out, outk, 0);
+                note_tile_cost(outk, guard);
                 mode = M_DONE;                          // shadow miss: record already says "traced, lit"
             }
         }
@@ -535,7 +566,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
                     }
                     valid = k; pux = ux; puy = uy; puz = uz;
-                    plev = (int)((word >> 26) & 15u);               // the reference node's level: it spans 2^(levels - level) cells
+                    plev = (int)((word >> 25) & 31u);               // the reference node's level: it spans 2^(levels - level) cells
                     low = (1 << (levels - plev)) - 1;
                     const uint32_t type = node_type(word);
                     what = type == EMPTY ? S_ADVANCE : type == LEAF ? S_HIT_LEAF : S_ENTER;
@@ -806,6 +837,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && outk < 0) {
             store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
+            note_tile_cost(outk, guard);
             mode = M_DONE;
         }
         if (run_hit && mode == M_HIT) {
@@ -833,6 +865,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             const V3 n = face ? face_normal(point, vlo, vlo + vsize, beta) : cube_normal_pow2(point, vlo, vsize, eps);
             const uint32_t flags = SVO_HIT_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u) | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
             store_hit(A.out, outk, tw, n, material, flags, (uint32_t)ci, node, hitc);
+            note_tile_cost(outk, guard);
             mode = M_DONE;
             if (A.shadow) {                             // the lane becomes its own shadow ray
                 alpha = point; beta = sdir; g = sg;

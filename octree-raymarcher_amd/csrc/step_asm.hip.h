@@ -185,7 +185,7 @@ __device__ __forceinline__ void march_steps_asm(
         "3:\n\t"
         "v_cmpx_gt_i32 vcc, -2.0, %[w]\n\t"                    // BRANCH entry (top bits 10): one more wide level
         "s_cbranch_execz 4f\n\t"
-        "v_and_b32 %[q3], 0x3ffffff, %[w]\n\t"
+        "v_and_b32 %[q3], 0x1ffffff, %[w]\n\t"
         "v_add_u32 %[val], 1, %[val]\n\t"
         "v_sub_u32 %[q4], %[nw], %[val]\n\t"
         "v_lshl_add_u32 %[q2], %[val], 8, %[lds]\n\t"
@@ -203,7 +203,7 @@ __device__ __forceinline__ void march_steps_asm(
         "s_branch 3b\n\t"
         "4:\n\t"
         "s_mov_b64 exec, %[smar]\n\t"
-        "v_bfe_u32 %[plv], %[w], 26, 4\n\t"                    // the reference node's level
+        "v_bfe_u32 %[plv], %[w], 25, 5\n\t"                    // the reference node's level
         "v_cmp_gt_u32_e64 %[sstay], 2.0, %[w]\n\t"             // EMPTY (type bits 00)
         "v_cmp_le_u32_e64 %[sent], -2.0, %[w]\n\t"             // TWIG  (type bits 11)
         "v_mov_b32 %[pux], %[ux]\n\t"
@@ -260,7 +260,7 @@ __device__ __forceinline__ void march_steps_asm(
         "v_cndmask_b32_e64 %[r3], %[r3], %[q7], %[sstay]\n\t"
         "v_sub_u32 %[q5], 1, %[crp]\n\t"                       // |creepn| + 1
         "v_cmp_lt_f32 vcc, %[r3], %[r2]\n\t"                   // glm::min(t.y, t.z) = (t.z < t.y) ? t.z : t.y
-        "v_and_b32 %[q6], 0x3ffffff, %[w]\n\t"                 // (entering lanes) brick index ...
+        "v_and_b32 %[q6], 0x1ffffff, %[w]\n\t"                 // (entering lanes) brick index ...
         "v_add_u32 %[q6], %[tof], %[q6]\n\t"
         "v_cndmask_b32 %[r2], %[r2], %[r3], vcc\n\t"
         "v_cmp_lt_f32 vcc, %[r2], %[r1]\n\t"                   // glm::min(t.x, .)

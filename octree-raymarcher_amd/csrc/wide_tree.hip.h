@@ -4,7 +4,7 @@
 // dependent load per level.  On upload every chunk's tree[] is also expanded into WIDE nodes of 4x4x4 = 64 entries: the
 // wide node of a BRANCH at level L holds, for each of its 64 grandchild positions, what a descent from that BRANCH ends
 // in after at most two levels -
-//     terminal  [type:2 | level:4 | payload:26]   EMPTY / LEAF (payload = material) / TWIG (payload = brick index) and the
+//     terminal  [type:2 | level:5 | payload:25]   EMPTY / LEAF (payload = material) / TWIG (payload = brick index) and the
 //                                                 level of the reference node (a child of the BRANCH, level L+1, fills
 //                                                 the 8 positions it covers; a grandchild, level L+2, fills one), or
 //     branch    [2 | 0 | wide node index]         the grandchild is a BRANCH itself: descend into its wide node.
@@ -26,7 +26,8 @@
 
 namespace svo {
 
-constexpr uint32_t WIDE_LEVEL_SHIFT = 26, WIDE_PAYLOAD_MASK = (1u << 26) - 1u;
+constexpr uint32_t WIDE_LEVEL_SHIFT = 25, WIDE_LEVEL_BITS = 5, WIDE_PAYLOAD_MASK = (1u << 25) - 1u;
+constexpr uint32_t WIDE_MAX_LEVELS = 22;        // branch levels the stack kernel marches (chunk depth <= 24: cell coordinates stay exact floats)
 
 __device__ __forceinline__ uint32_t wide_terminal(uint32_t word, uint32_t level)
 {   // word: a reference node word that is not a BRANCH

@@ -31,6 +31,8 @@ struct svo_world {
     uint64_t wide_pool_len = 0, wide_pool_cap = 0, wide_nodes_used = 0;
     uint32_t *d_wscratch = nullptr;               // builder scratch: fronts, flags, ranks
     uint64_t wscratch_words = 0;
+    void *d_sort = nullptr;                       // svo_tile_order scratch
+    size_t sort_bytes = 0;
     bool wide_ok = false;                         // every chunk's bricks fit the 26-bit payload
     unsigned long long *d_work = nullptr;         // WORK_SLOTS x {tile cursor, rays marched}: one slot per launch in flight
     unsigned work_next = 0, work_last = 0;        // ring cursor; slot of the most recent launch

@@ -26,11 +26,11 @@ def test_library_exports_every_declared_symbol(svo):
     out = subprocess.run(["nm", "-D", "--defined-only", svo.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(re.findall(r" T (svo_[a-z0-9_]+)$", out, flags=re.M)))
     assert exported == names, "exported svo_* symbols differ from the header"
-    assert svo.lib.svo_abi_version() == 2
+    assert svo.lib.svo_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header(svo):
-    assert C.sizeof(svo.ChunkDesc) == 56 and C.sizeof(svo.Camera) == 64 and C.sizeof(svo.TraceParams) == 56
+    assert C.sizeof(svo.ChunkDesc) == 56 and C.sizeof(svo.Camera) == 64 and C.sizeof(svo.TraceParams) == 72
     assert C.sizeof(svo.TerrainParams) == 68 and svo.HIT_DTYPE.itemsize == 32
     # compile a C translation unit against the header and print the same sizes
     src = r'''#include "svo.h"

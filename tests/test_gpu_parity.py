@@ -677,3 +677,46 @@ def test_tiny_images_and_extreme_fields_of_view(svo, oracle, worlds, kernel):
             cam = svo.make_camera((130.3, 150.0, -40.0), (0.1, -0.5, 0.85), (0.0, 1.0, 0.0), fov, w, h)
             want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=4)
             assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=_kid(svo, kernel)), want, f"{w}x{h} fov {fov}/{kernel}")
+
+
+def test_tile_order_changes_nothing_but_the_schedule(svo, oracle, worlds):
+    """svo_trace_params.tile_cost_dev / tile_order_dev: a frame records its tiles' step maxima,
+    svo_tile_order sorts the tiles by them, the next frame hands them out in that order - and writes the same records,
+    byte for byte, as without an order (and as the oracle).  Also over two frames in one launch."""
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 200, 120)
+    w, h = cam.width, cam.height
+    ntiles = ((w + 7) // 8) * ((h + 7) // 8)
+    out = svo.DeviceBuffer(2 * w * h * 32)
+    cost = svo.DeviceBuffer.from_numpy(np.full((2, ntiles, 2), 0xDEAD, np.uint32))     # the launch clears what it records into
+    order = svo.DeviceBuffer(ntiles * 4)
+    prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tile_cost_dev=cost.ptr)
+    W.trace(cam, prm, (0, 0, w, h), out.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    plain = out.to_numpy(svo.HIT_DTYPE, w * h).copy()
+    c = cost.to_numpy(np.uint32, 2 * ntiles * 2).reshape(2, ntiles, 2)
+    assert c[0, :, 0].max() > c[0, :, 0].min() and c[0, :, 1].max() > 0          # (a tile whose rays all miss the world box records nothing)
+    assert np.all(c[1] == 0xDEAD)                                           # one frame traced: the second frame's slots untouched
+    W.tile_order(cost.ptr, order.ptr, ntiles)
+    svo.lib.svo_stream_synchronize(None)
+    od = order.to_numpy(np.uint32, ntiles)
+    assert np.array_equal(np.sort(od), np.arange(ntiles, dtype=np.uint32))
+    key = c[0, :, 0].astype(np.int64) + c[0, :, 1]
+    assert np.all(np.diff(key[od]) <= 0), "tiles are handed out by descending cost"
+    want = O.trace_image(cam, params=oracle.make_params(shadow=True), threads=8)
+    assert_gbuffer_equal(plain.reshape(h, w), want, "plain frame")
+    prm2 = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tile_cost_dev=cost.ptr, tile_order_dev=order.ptr)
+    W.trace_frames([cam, cam], prm2, (0, 0, w, h), out.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    both = out.to_numpy(svo.HIT_DTYPE, 2 * w * h)
+    assert both[:w * h].tobytes() == plain.tobytes() and both[w * h:].tobytes() == plain.tobytes()
+    c2 = cost.to_numpy(np.uint32, 2 * ntiles * 2).reshape(2, ntiles, 2)
+    assert np.array_equal(c2[0] > 0, c[0] > 0) and np.array_equal(c2[1] > 0, c2[0] > 0)
+    # a reversed order (shortest first) is a schedule like any other
+    rev = svo.DeviceBuffer.from_numpy(od[::-1].copy())
+    prm3 = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tile_order_dev=rev.ptr)
+    W.trace(cam, prm3, (0, 0, w, h), out.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    assert out.to_numpy(svo.HIT_DTYPE, w * h).tobytes() == plain.tobytes()
+    for b in (out, cost, order, rev):
+        b.free()
