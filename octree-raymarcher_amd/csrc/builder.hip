@@ -15,6 +15,9 @@
 // row-major): mip kernels read/write whole rows coalesced; frontier entries are 16 B {x, y, z, slot}.
 // Compile with -ffp-contract=off: every float op must round separately, exactly like terrain.cpp.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -389,6 +392,10 @@ __global__ __launch_bounds__(256) void k_brick_fill(uint16_t *twig, const DevBri
 // exactly as svo_world_upload packs them; the world is uploaded to `device` when this returns.
 static int generate_world_resident_impl(svo_world &w, int device)
 {
+    const bool timing = std::getenv("SVO_BUILD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lapt = [&](const char *what) { if (timing) { (void)hipDeviceSynchronize(); const double t1 = now(); std::fprintf(stderr, "[svo build] %-28s %.1f ms\n", what, (t1 - t0) * 1e3); t0 = t1; } };
     const TerrainParams &tp = w.terrain;
     const int gw = w.width, gh = w.height, gd = w.depth, chunksize = w.chunksize;
     const int *ccm = w.chunkcoordmin;
@@ -424,6 +431,7 @@ static int generate_world_resident_impl(svo_world &w, int device)
                 }
             }
     }
+    lapt("noise + mips + grow (device)");
     if (tp.water) {     // Ocroot::build on the node words (host threads, all chunks in parallel); brick edits are recorded
         int nthreads = tp.threads > 0 ? tp.threads : (int)std::thread::hardware_concurrency();
         nthreads = std::max(1, std::min<int>(nthreads, (int)chunks.size()));
@@ -449,10 +457,12 @@ static int generate_world_resident_impl(svo_world &w, int device)
         for (auto &t : pool) t.join();
         if (failed.load()) { set_error("svo_world_generate: out of host memory in the water fill"); return SVO_ERR_OUT_OF_MEMORY; }
     }
+    lapt("water fill plan (host)");
     // pack: the layout of svo_world_upload
     int rc = plan_pools(w);
     if (rc != SVO_OK) return rc;
     if ((rc = alloc_pools(w, device)) != SVO_OK) return rc;
+    lapt("alloc pools");
     DevBuf<DevBrickOp> d_ops;
     for (size_t i = 0; i < chunks.size(); ++i) {
         ChunkPools &c = chunks[i];
@@ -476,8 +486,10 @@ static int generate_world_resident_impl(svo_world &w, int device)
         BUILD_TRY(hipStreamSynchronize(s));
         (void)hipFree(bricks[i]); bricks[i] = nullptr;
     }
+    lapt("pack + brick fill + masks");
     BUILD_TRY(hipMemcpy(w.d_chunks, w.table.data(), chunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice));
     if ((rc = build_wide_all(w, s)) != SVO_OK) return rc;
+    lapt("wide trees");
     BUILD_TRY(hipDeviceSynchronize());
     return SVO_OK;
 }

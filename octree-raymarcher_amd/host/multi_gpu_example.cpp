@@ -1,10 +1,11 @@
-// multi_gpu_example.cpp — World::draw over N devices of one node (multi_gpu.hpp), checked against the single-device frame.
+// multi_gpu_example.cpp — World::draw over N devices of one node (multi_gpu.hpp), checked against single-device frames.
 //
 //   hipcc -std=c++17 -I. multi_gpu_example.cpp -L.. -lsvo_amd -lrccl -Wl,-rpath,'$ORIGIN/..' -o multi_gpu_example
 //   ./multi_gpu_example <devices> [depth] [width height]
 //
-// exit 0: the gathered, de-interleaved frame equals the frame device 0 traces alone, record for record;
-// exit 1: it differs;  exit 3: fewer devices than asked for (nothing was run).
+// Two draw_frames() calls in flight (3 views, then 2: both slots), every gathered, de-interleaved frame compared with the
+// frame device 0 traces alone.
+// exit 0: all equal, record for record;  exit 1: some differ;  exit 3: fewer devices than asked for (nothing was run).
 #include <cstdio>
 #include <cstdlib>
 
@@ -22,25 +23,33 @@ int main(int argc, char **argv)
     }
     try {
         svo::MultiGpuWorld node(ndev, 2, 1, 2, 128, depth);
-        svo::Camera cam({ 128.0f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, { 0.0f, 1.0f, 0.0f }, 60.0f, w, h);
-        const uint64_t *frame_dev = node.draw(cam, true);
+        std::vector<svo::Camera> views;
+        for (int f = 0; f < 5; ++f)
+            views.emplace_back(svo::vec3{ 128.0f + 7.0f * (float)f, 150.0f - 3.0f * (float)f, -40.0f }, svo::vec3{ 0.03f * (float)f, -0.5f, 0.866f }, svo::vec3{ 0.0f, 1.0f, 0.0f }, 60.0f, w, h);
+        const std::vector<svo::Camera> first(views.begin(), views.begin() + 3), second(views.begin() + 3, views.end());
+        int slot_a = -1, slot_b = -1;
+        const uint64_t *fa = node.draw_frames(first, true, nullptr, &slot_a);
+        const size_t stride_a = node.frame_stride(slot_a);
+        const uint64_t *fb = node.draw_frames(second, true, nullptr, &slot_b);      // in flight behind the first call
+        const size_t stride_b = node.frame_stride(slot_b);
         node.wait();
-        std::vector<uint64_t> frame((size_t)w * h);
-        svo::hip_check(hipMemcpy(frame.data(), frame_dev, frame.size() * 8, hipMemcpyDeviceToHost), "hipMemcpy");
-
-        // the same frame traced by device 0 alone
-        svo::GBuffer whole(w, h);
-        node.world(0).draw(cam, whole, true);
-        uint64_t *packed = static_cast<uint64_t *>(svo_device_alloc((size_t)w * h * 8));
-        svo::check(svo_gbuffer_pack(whole.device(), packed, (int64_t)w * h, nullptr), "svo_gbuffer_pack");
-        std::vector<uint64_t> ref((size_t)w * h);
-        svo::check(svo_memcpy_d2h(ref.data(), packed, ref.size() * 8), "svo_memcpy_d2h");
-        svo_device_free(packed);
 
         size_t differ = 0, hits = 0;
-        for (size_t i = 0; i < ref.size(); ++i) { differ += frame[i] != ref[i]; hits += (ref[i] >> 48) & 1u; }
-        std::printf("multi_gpu_example: %d device(s), %dx%d, depth %u: %zu hit pixels, %zu records differ from the single-device frame\n",
-                    ndev, w, h, depth, hits, differ);
+        svo::GBuffer whole(w, h);
+        uint64_t *packed = static_cast<uint64_t *>(svo_device_alloc((size_t)w * h * 8));
+        std::vector<uint64_t> frame((size_t)w * h), ref((size_t)w * h);
+        for (int f = 0; f < 5; ++f) {
+            const uint64_t *src = f < 3 ? fa + (size_t)f * stride_a : fb + (size_t)(f - 3) * stride_b;
+            svo::hip_check(hipMemcpy(frame.data(), src, frame.size() * 8, hipMemcpyDeviceToHost), "hipMemcpy");
+            node.world(0).draw(views[(size_t)f], whole, true);                      // the same view traced by device 0 alone
+            svo::check(svo_gbuffer_pack(whole.device(), packed, (int64_t)w * h, nullptr), "svo_gbuffer_pack");
+            svo::check(svo_memcpy_d2h(ref.data(), packed, ref.size() * 8), "svo_memcpy_d2h");
+            for (size_t i = 0; i < ref.size(); ++i) { differ += frame[i] != ref[i]; hits += (ref[i] >> 48) & 1u; }
+        }
+        svo_device_free(packed);
+        std::printf("multi_gpu_example: %d device(s), 5 frames of %dx%d in two calls (slots %d, %d), depth %u: %d point-to-point ops + %d strided copies per 3-frame call; "
+                    "%zu hit pixels, %zu records differ from the single-device frames\n",
+                    ndev, w, h, slot_a, slot_b, depth, node.exchange_ops(), node.copy_ops(3), hits, differ);
         return differ ? 1 : 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "multi_gpu_example: %s\n", e.what());

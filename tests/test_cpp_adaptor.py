@@ -34,7 +34,7 @@ MULTI = os.path.join(HOST, "multi_gpu_example")
 
 
 def build_multi():
-    """The C++ multi-GPU host (multi_gpu.hpp: N devices in one process, svo_trace_rows + svo_gbuffer_pack per device,
+    """The C++ multi-GPU host (multi_gpu.hpp: N devices in one process, svo_trace_rows_frames + svo_gbuffer_pack per device, one
     grouped ncclSend / ncclRecv of the bands into their rows of the frame on device 0) links against librccl."""
     subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I.", "multi_gpu_example.cpp", "-L..", "-lsvo_amd",
                     "-lrccl", "-Wl,-rpath,$ORIGIN/..", "-o", "multi_gpu_example"], cwd=HOST, check=True)
