@@ -572,6 +572,7 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     const float inv = 1.0f / std::sqrt(nx * nx + ny * ny + nz * nz);
     A.sdir[0] = nx * inv; A.sdir[1] = ny * inv; A.sdir[2] = nz * inv;
     A.counters = prm ? prm->counters_dev : nullptr;
+    A.exact_geometry = w->exact_geometry ? 1 : 0;
     A.tile_cost = prm ? prm->tile_cost_dev : nullptr;
     A.tile_order = prm ? prm->tile_order_dev : nullptr;
     A.work = w->d_work;                 // the launch picks its slot

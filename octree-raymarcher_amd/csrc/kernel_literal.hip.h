@@ -13,6 +13,58 @@ namespace svo {
 
 struct LitCounters { uint32_t node_words, brick_cells, chunk_descs, tree_steps; };
 
+// Creeping rays in closed form (see the creep block of kernel_stack.hip.h for the argument): a ray that sits exactly on the
+// lower face of an empty cell [lo, lo + size) on an axis it moves down along gets cubeEscapeDistance == -0 and advances by
+// EPS alone (src/Traverse.cpp:25-32 has no guard) - for thousands of steps.  After one such step, lit_creep_run returns how
+// many FURTHER consecutive steps are of that kind, K >= 0: while the position q_k = a + b*t_k stays inside the cell
+// (lo <= q_k < hi on every axis; for a brick cell also the reference's own truncated cell index, :58), an axis pinned at the
+// first of them stays pinned (monotone), the escape is -0 and t_{k+1} = t_k + EPS - and that sum is exact while t_0 and EPS
+// (a power of two) are multiples of ulp(t_k), so t_k = t_0 + k*EPS without rounding.  K is found by doubling + bit descent
+// (~2 log2 K probes); the caller then takes the K steps at once: same t, same counters, caps honoured (kmax).
+__device__ inline int lit_creep_run(V3 a, V3 b, V3 g, float t0, V3 lo, float size, float eps, int kmax,
+                                    bool brick, V3 blo, float voxel)
+{
+    const uint32_t eb = __float_as_uint(eps);
+    const bool eps_pow2 = (eb & 0x807FFFFFu) == 0u && eb >= 0x00800000u && eb < 0x7F800000u;
+    const float fmax = __uint_as_float(0x7F7FFFFFu);
+    if (!eps_pow2 || kmax <= 0 || !(fabsf(g.x) <= fmax) || !(fabsf(g.y) <= fmax) || !(fabsf(g.z) <= fmax)) return 0;
+    const V3 hi = lo + size;
+    const V3 q0 = a + b * t0;
+    bool go = (q0.x >= lo.x) & (q0.y >= lo.y) & (q0.z >= lo.z) & (q0.x < hi.x) & (q0.y < hi.y) & (q0.z < hi.z);
+    go &= ((b.x < 0.0f) & (q0.x == lo.x)) | ((b.y < 0.0f) & (q0.y == lo.y)) | ((b.z < 0.0f) & (q0.z == lo.z));
+    float fvx = 0.0f, fvy = 0.0f, fvz = 0.0f;
+    if (brick) {        // the cell the reference's truncation finds for q0 must be this one
+        const V3 f = (q0 - blo) / voxel;
+        fvx = (float)(int)f.x; fvy = (float)(int)f.y; fvz = (float)(int)f.z;
+        go &= (blo.x + fvx * voxel == lo.x) & (blo.y + fvy * voxel == lo.y) & (blo.z + fvz * voxel == lo.z);
+    }
+    if (!go) return 0;
+    const uint32_t t0b = __float_as_uint(t0);
+    const int e_eps = (int)(eb >> 23);
+    int K = 0;
+    bool up = true;
+    for (int bit = 1; bit > 0;) {
+        const int cand = up ? bit : K + bit;
+        const float tk = t0 + (float)(cand - 1) * eps;          // position before the cand-th step
+        const float tn = t0 + (float)cand * eps;                // parameter after it: must be exact
+        const int e_n = (int)(__float_as_uint(tn) >> 23), shift = e_n - (int)(t0b >> 23);
+        bool ok = cand <= kmax && e_n - 23 <= e_eps && tn < __uint_as_float(0x7F800000u);
+        ok = ok && (t0b == 0u || (t0b >= 0x00800000u && shift < 24 && (((t0b & 0x007FFFFFu) | 0x00800000u) & ((1u << (shift < 0 ? 0 : shift)) - 1u)) == 0u));
+        const V3 q = a + b * tk;
+        ok &= (q.x >= lo.x) & (q.y >= lo.y) & (q.z >= lo.z) & (q.x < hi.x) & (q.y < hi.y) & (q.z < hi.z);
+        if (brick) {
+            const V3 f = (q - blo) / voxel;
+            ok &= (f.x >= fvx) & (f.x < fvx + 1.0f) & (f.y >= fvy) & (f.y < fvy + 1.0f) & (f.z >= fvz) & (f.z < fvz + 1.0f);
+        }
+        K = ok ? cand : K;
+        if (!up) bit >>= 1;
+        else if (!ok) { up = false; bit >>= 2; }                // K <= bit/2, the bits below that are open
+        else if (bit >= (1 << 13)) { up = false; bit >>= 1; }
+        else bit <<= 1;
+    }
+    return K;
+}
+
 __device__ inline bool lit_brick(const TraceArgs &A, V3 a, V3 b, V3 g, V3 lo, float size, float voxel,
                                  const uint16_t *cells, float &s, Voxel &vox, LitCounters &cnt, uint32_t &guard)
 {
@@ -34,7 +86,13 @@ __device__ inline bool lit_brick(const TraceArgs &A, V3 a, V3 b, V3 g, V3 lo, fl
             vox.lo = vlo; vox.size = voxel; vox.material = m; vox.cell = word;
             return true;
         }
-        t += escape(p, g, vlo, vlo + voxel) + A.eps;
+        const float e = escape(p, g, vlo, vlo + voxel) + A.eps;
+        t += e;
+        if (A.exact_geometry && e < 2.0f * A.eps) {             // a pinned step: the following ones in closed form (exact corners: the cell test is the reference's)
+            const int K = lit_creep_run(a, b, g, t, vlo, voxel, A.eps, min(A.cap_twig - 1 - c, (int)(STEP_GUARD - guard)), true, lo, voxel);
+            t += (float)K * A.eps;
+            c += K; guard += (uint32_t)K; cnt.brick_cells += (uint32_t)K;
+        }
     }
     return false;
 }
@@ -54,8 +112,9 @@ __device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevC
         V3 lo = rlo;
         float size = rootsize;
         uint32_t node = 0, word;
+        uint32_t words = 0;                                     // node words this step reads (the same for every step into this leaf)
         for (int lv = 0;; ++lv) {
-            cnt.node_words++;
+            cnt.node_words++; words++;
             word = tree[node];
             if (node_type(word) != BRANCH || lv >= 32) break;
             const float half = size * 0.5f;
@@ -82,7 +141,13 @@ __device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevC
         } else if (type == BRANCH) {
             return false;                                   // deeper than 32 levels: malformed
         }
-        t += escape(p, g, lo, lo + size) + A.eps;
+        const float e = escape(p, g, lo, lo + size) + A.eps;
+        t += e;
+        if (A.exact_geometry && type == EMPTY && e < 2.0f * A.eps) {   // a pinned step over an EMPTY node: the following ones in closed form
+            const int K = lit_creep_run(a, b, g, t, lo, size, A.eps, min(A.cap_tree - 1 - i, (int)(STEP_GUARD - guard)), false, lo, size);
+            t += (float)K * A.eps;
+            i += K; guard += (uint32_t)K; cnt.tree_steps += (uint32_t)K; cnt.node_words += (uint32_t)K * words;
+        }
     }
     return false;
 }

@@ -97,6 +97,7 @@ struct TraceArgs {
     uint32_t *counters;         // optional [n][4]
     unsigned long long *work;   // launch slot: [1] rays marched, [WORK_CURSOR0 + r] tile cursor of screen region r
     int32_t  ntiles, tiles_per_row;     // 8x8 tiles of ONE frame's raster (64-ray groups of the list in list mode)
+    int32_t  exact_geometry;    // every voxel corner is an exact float (svo_world_info.exact_geometry): the literal kernel's closed-form creep runs rely on it
     uint32_t *tile_cost;        // optional [nframes][ntiles][2]: largest primary / shadow step count per tile (stack kernel)
     const uint32_t *tile_order; // optional [ntiles]: the order in which a frame's tiles are handed out (stack kernel)
 };
