@@ -23,7 +23,7 @@
 #define SVO_STACK_REFILL 8       // retired lanes per wave that trigger a refill (cheap: rays are staged in LDS)
 #endif
 #ifndef SVO_STACK_WAVES
-#define SVO_STACK_WAVES 5        // waves per SIMD the stack kernel is register-budgeted for (natural allocation)
+#define SVO_STACK_WAVES 6        // waves per SIMD the stack kernel is register-budgeted for: 80 VGPRs (the asm step holds 63; spills sit in the rare blocks)
 #endif
 
 #include "kernel_literal.hip.h"

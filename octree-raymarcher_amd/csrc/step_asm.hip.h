@@ -48,9 +48,9 @@ __device__ __forceinline__ void march_steps_asm(
     const V3 beta, const V3 g, const V3 clo, const V3 alpha, const int levels, const int nw, const float res_tree,
     const uint32_t wide_b, const uint32_t twig_off, const uint32_t lds_lane, const StepUniform U, const int nsteps)
 {
-    float px, py, pz, fx, fy, fz, q1, q2, q3, q4, q5, q6, q7, r1, r2, r3;
-    int ux, uy, uz, low, ir;
-    uint32_t w, wc;
+    float px, py, pz, q1, q2, q3, q4, q5, q6, q7, r1, r2, r3;     // (r1..r3 double as the lattice quotients, low as 1/res, q7 as the brick cell index)
+    int ux, uy, uz, low;
+    uint32_t w;
     unsigned long long sall, smar, stw, sstay, sadv, sent, q64;
     int sctr;
     asm volatile(
@@ -65,29 +65,29 @@ __device__ __forceinline__ void march_steps_asm(
         "v_mul_f32 %[px], %[bx], %[t]\n\t"
         "v_mul_f32 %[py], %[by], %[t]\n\t"
         "v_mul_f32 %[pz], %[bz], %[t]\n\t"
-        "v_sub_u32 %[ir], 0x7f000000, %[rs]\n\t"               // 1/res, res a power of two
+        "v_sub_u32 %[low], 0x7f000000, %[rs]\n\t"               // 1/res, res a power of two
         "v_add_f32 %[px], %[ox], %[px]\n\t"
         "v_add_f32 %[py], %[oy], %[py]\n\t"
         "v_add_f32 %[pz], %[oz], %[pz]\n\t"
         "v_add_u32 %[cnt], -1, %[cnt]\n\t"                     // steps left of the level's cap, this one taken
-        "v_sub_f32 %[fx], %[px], %[lx]\n\t"
-        "v_sub_f32 %[fy], %[py], %[ly]\n\t"
-        "v_sub_f32 %[fz], %[pz], %[lz]\n\t"
+        "v_sub_f32 %[r1], %[px], %[lx]\n\t"
+        "v_sub_f32 %[r2], %[py], %[ly]\n\t"
+        "v_sub_f32 %[r3], %[pz], %[lz]\n\t"
         "v_sub_u32 %[q7], 0, %[crp]\n\t"
-        "v_mul_f32 %[fx], %[fx], %[ir]\n\t"
-        "v_mul_f32 %[fy], %[fy], %[ir]\n\t"
-        "v_mul_f32 %[fz], %[fz], %[ir]\n\t"
+        "v_mul_f32 %[r1], %[r1], %[low]\n\t"
+        "v_mul_f32 %[r2], %[r2], %[low]\n\t"
+        "v_mul_f32 %[r3], %[r3], %[low]\n\t"
         "v_min_i32 %[crp], %[crp], %[q7]\n\t"                  // creepn = -|creepn|: disarmed unless this step advances
-        "v_cvt_i32_f32 %[ux], %[fx]\n\t"
-        "v_cvt_i32_f32 %[uy], %[fy]\n\t"
-        "v_cvt_i32_f32 %[uz], %[fz]\n\t"
+        "v_cvt_i32_f32 %[ux], %[r1]\n\t"
+        "v_cvt_i32_f32 %[uy], %[r2]\n\t"
+        "v_cvt_i32_f32 %[uz], %[r3]\n\t"
         // ---- tree level, first half: start the descent (src/Traverse.cpp:34-48 through the wide tree and the descent
         //      cache) for every marching tree lane, before it is known whether the lane stays in its box
         "s_andn2_b64 exec, %[smar], %[stw]\n\t"
         "s_cbranch_execz 20f\n\t"
-        "v_fract_f32 %[q1], %[fx]\n\t"                         // integral quotient: p on (or rounded onto) a lattice plane
-        "v_fract_f32 %[q2], %[fy]\n\t"
-        "v_fract_f32 %[q3], %[fz]\n\t"
+        "v_fract_f32 %[q1], %[r1]\n\t"                         // integral quotient: p on (or rounded onto) a lattice plane
+        "v_fract_f32 %[q2], %[r2]\n\t"
+        "v_fract_f32 %[q3], %[r3]\n\t"
         "v_xor_b32 %[q4], %[ux], %[pux]\n\t"
         "v_min3_f32 %[q1], %[q1], %[q2], %[q3]\n\t"
         "v_xor_b32 %[q5], %[uy], %[puy]\n\t"
@@ -163,17 +163,17 @@ __device__ __forceinline__ void march_steps_asm(
         //      means it has arrived (20: below waits for it where no descent load was issued)
         "s_and_b64 exec, %[sstay], %[stw]\n\t"
         "s_cbranch_execz 5f\n\t"
-        "v_lshl_add_u32 %[wc], %[uz], 2, %[uy]\n\t"
+        "v_lshl_add_u32 %[q7], %[uz], 2, %[uy]\n\t"
         "v_mov_b32 %[low], 0\n\t"
-        "v_lshl_add_u32 %[wc], %[wc], 2, %[ux]\n\t"            // cell index z*16 + y*4 + x
-        "v_sub_u32 %[q1], 63, %[wc]\n\t"
+        "v_lshl_add_u32 %[q7], %[q7], 2, %[ux]\n\t"            // cell index z*16 + y*4 + x
+        "v_sub_u32 %[q1], 63, %[q7]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
         "v_lshlrev_b64 %[q64], %[q1], %[bm]\n\t"                // the cell's bit of the occupancy mask -> sign bit
         "v_cmp_gt_i64 vcc, 0, %[q64]\n\t"                       // occupied
         "s_andn2_b64 %[sadv], exec, vcc\n\t"
         "s_and_b64 exec, exec, vcc\n\t"                         // occupied: hit, :63,101,160
         "v_add_f32 %[q1], %[t], %[tts]\n\t"
-        "v_mov_b32 %[cnt], %[wc]\n\t"
+        "v_mov_b32 %[cnt], %[q7]\n\t"
         "v_mov_b32 %[md], 2\n\t"
         "v_add_f32 %[tw], %[tw], %[q1]\n\t"
         "5:\n\t"
@@ -338,10 +338,9 @@ __device__ __forceinline__ void march_steps_asm(
           [bs] "+v"(bsize), [rs] "+v"(res), [t] "+v"(t), [cnt] "+v"(cnt), [tts] "+v"(tt_saved), [tms] "+v"(t_miss), [its] "+v"(it_saved),
           [tw] "+v"(tw), [cw] "+v"(cw), [pux] "+v"(pux), [puy] "+v"(puy), [puz] "+v"(puz), [val] "+v"(valid), [plv] "+v"(plev),
           [bm] "+v"(bmask), [crp] "+v"(creepn),
-          [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [fx] "=&v"(fx), [fy] "=&v"(fy), [fz] "=&v"(fz),
-          [ux] "=&v"(ux), [uy] "=&v"(uy), [uz] "=&v"(uz),
+          [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [ux] "=&v"(ux), [uy] "=&v"(uy), [uz] "=&v"(uz),
           [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [q4] "=&v"(q4), [q5] "=&v"(q5), [q6] "=&v"(q6), [q7] "=&v"(q7),
-          [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [low] "=&v"(low), [ir] "=&v"(ir), [w] "=&v"(w), [wc] "=&v"(wc), [q64] "=&v"(q64),
+          [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [low] "=&v"(low), [w] "=&v"(w), [q64] "=&v"(q64),
           [sall] "=&s"(sall), [smar] "=&s"(smar), [stw] "=&s"(stw), [sstay] "=&s"(sstay), [sadv] "=&s"(sadv), [sent] "=&s"(sent), [sctr] "=&s"(sctr)
         : [bx] "v"(beta.x), [by] "v"(beta.y), [bz] "v"(beta.z), [gx] "v"(g.x), [gy] "v"(g.y), [gz] "v"(g.z),
           [clx] "v"(clo.x), [cly] "v"(clo.y), [clz] "v"(clo.z), [ax] "v"(alpha.x), [ay] "v"(alpha.y), [az] "v"(alpha.z),
