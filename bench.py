@@ -487,7 +487,7 @@ def run(args):
     # by the previous frame's per-tile step maxima (svo_trace_params.tile_cost_dev -> svo_tile_order -> tile_order_dev).
     # The ordered figure includes the sort.  Records must be byte-identical either way.
     single = None
-    if not multi and not share and args.kernel != "literal" and world.info.wide_nodes > 0:
+    if not multi and not share and not args.no_diagnostics and args.kernel != "literal" and world.info.wide_nodes > 0:
         st0 = streams[0]
         ntl = ((iw + 7) // 8) * ((ih + 7) // 8)
         cost = torch.zeros(ntl * 2, dtype=torch.int32, device=dev)
@@ -630,15 +630,21 @@ def run(args):
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
                 "counters_all_path_cameras": counters_sum,
             }
-            if prof.get("valu_insts_per_frame"):
-                # VALU issue: cycles per wave64 instruction per SIMD measured by scripts/microbench/valu_issue.hip
-                cyc = float(prof.get("valu_cycles_per_inst", 2.45))
+            if prof.get("issue"):
+                # instruction issue: ONE figure with its spread, measured by scripts/prof_round3.sh + scripts/microbench/valu_issue
+                # on the serialized 8-frame launch and replayed here; "this_run" prices the profiled instruction count per frame
+                # against this run's time per frame at the nominal 2.4 GHz shader clock
+                iss = prof["issue"]
                 simd_cycles = 1024 * 2.4e9 * (elapsed / args.steps)
-                result["roofline"]["valu_issue"] = {
-                    "insts_per_frame": int(prof["valu_insts_per_frame"]), "cycles_per_inst": cyc,
-                    "frac_of_issue_slots": round(prof["valu_insts_per_frame"] * cyc / simd_cycles, 4),
+                result["roofline"]["issue"] = {
+                    "instructions_per_frame": int(iss["instructions_per_frame"]), "valu_per_frame": int(iss["valu_per_frame"]), "salu_per_frame": int(iss["salu_per_frame"]),
+                    "cycles_per_instruction": iss["cycles_per_instruction_weighted"], "cycles_per_instruction_spread": iss["spread_p10_p90_over_simds"],
+                    "issue_utilisation_profiled_launch": iss["issue_utilisation"], "issue_utilisation_spread": iss["issue_utilisation_spread"],
+                    "issue_utilisation_this_run_at_2.4GHz": round(iss["instructions_per_frame"] * iss["cycles_per_instruction_weighted"] / simd_cycles, 4),
+                    "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
-                    "note": "SQ_INSTS_VALU per one-frame launch x measured cycles per wave64 VALU instruction / (1024 SIMDs x 2.4 GHz x s per frame)"}
+                    "note": "the march is bound by its chain of dependent loads per wave-step, not by issue: 22 % fewer instructions changed nothing at 5 waves per SIMD, "
+                            "a sixth wave per SIMD gave 9 % (DESIGN.md §5)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
