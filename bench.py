@@ -279,7 +279,7 @@ def run(args):
     P = len(path)
     # a 1/N share of the frame is small: with several frames in flight, waves that keep refilling (>= 4 tiles each) beat
     # one wave per tile (+6 % at 1/8 share); no effect on a full 1080p frame, which has more tiles than resident waves
-    prm = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)
+    prm = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)        # (launches_in_flight is set below, once S is known)
     # launches in flight: a launch's critical path is its longest ray, so its tail leaves SIMDs idle that the next
     # launches' bulk fills; with N ranks a rank's share of a frame shrinks N-fold, so more frames ride in one launch
     # (both tables measured with --emulate-share on ONE GPU; unmeasured on real multi-GPU hardware)
@@ -297,6 +297,8 @@ def run(args):
         G = max(1, min(G, args.steps // S))     # a short run: fewer frames per launch rather than idle streams
     if args.kernel == "literal":
         G = 1                                   # the literal kernel is one launch per frame (svo_trace_last_ray_count reports one frame)
+    prm.launches_in_flight = S                  # the timed launches share the wave slots (svo_trace_params.launches_in_flight)
+    prm_alone = svo.trace_params(shadow=shadow, kernel=kernel, tiles_per_wave=4)       # serialized legs: one launch owns the device
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -470,9 +472,9 @@ def run(args):
         for ci, c in enumerate(path):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(st0):
-                world.trace_frames([c] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames([c] * G, prm_alone, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 a.record(st0)
-                world.trace_frames([c] * G, prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames([c] * G, prm_alone, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 b.record(st0)
             st0.synchronize()
             per_cam.append(rays_cam[ci] * G / (a.elapsed_time(b) * 1e-3) / 1e6)
@@ -543,7 +545,7 @@ def run(args):
         with torch.cuda.stream(st0):
             for j, (a, b) in enumerate(sev):
                 a.record(st0)
-                world.trace_frames(cams_of(j * G, G), prm, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames(cams_of(j * G, G), prm_alone, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 b.record(st0)
                 roof_bytes += sum(algo_cam[(j * G + f) % P] for f in range(G))
         st0.synchronize()

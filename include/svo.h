@@ -158,7 +158,11 @@ typedef struct svo_trace_params {
                                        alpha + beta*(t - EPS) lies closest to (axis of the largest |point - centre|, first axis
                                        on ties; signed like that component, against the ray if it is exactly 0) - the face the
                                        ray entered through, defined for every hit; such records carry SVO_FACE_NORMAL */
-    int32_t  _reserved;
+    int32_t  launches_in_flight;    /* SVO_KERNEL_STACK launch shape: how many launches of this world the caller keeps in flight on different
+                                       streams (0 / 1 = one: the launch takes every wave slot of the device - shortest single launch).
+                                       With n >= 2 a launch takes 2/n of the wave slots, so that at least two launches are resident
+                                       side by side and one's drain (its longest rays) runs under another's bulk instead of
+                                       holding slots the next launch waits for.  Never changes the records */
     /* Frame-to-frame tile scheduling for the shortest SINGLE frame (the reference's caller issues one World::draw per
      * displayed frame, src/Main.cpp:190-222).  A frame takes as long as its bulk or its longest ray, whichever is longer;
      * handing the tiles out longest-first starts the long rays at once.  SVO_KERNEL_STACK only; both optional:

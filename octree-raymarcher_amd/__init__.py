@@ -82,7 +82,7 @@ class TraceParams(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_chunk_steps", C.c_int32), ("max_tree_steps", C.c_int32),
                 ("max_twig_steps", C.c_int32), ("shadow", C.c_int32), ("light_dir", C.c_float * 3),
                 ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p),
-                ("normal_mode", C.c_int32), ("_reserved", C.c_int32),
+                ("normal_mode", C.c_int32), ("launches_in_flight", C.c_int32),
                 ("tile_cost_dev", C.c_void_p), ("tile_order_dev", C.c_void_p)]
 
 
@@ -258,7 +258,7 @@ def c5_scene() -> dict:
 
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
                  caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0, normal_mode: int = 0,
-                 tile_cost_dev: Optional[int] = None, tile_order_dev: Optional[int] = None) -> TraceParams:
+                 tile_cost_dev: Optional[int] = None, tile_order_dev: Optional[int] = None, launches_in_flight: int = 0) -> TraceParams:
     p = TraceParams()
     p.normal_mode = normal_mode
     p.eps = eps
@@ -270,6 +270,7 @@ def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0
     p.tiles_per_wave = tiles_per_wave
     p.tile_cost_dev = tile_cost_dev
     p.tile_order_dev = tile_order_dev
+    p.launches_in_flight = launches_in_flight
     return p
 
 

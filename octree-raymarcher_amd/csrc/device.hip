@@ -105,7 +105,7 @@ int release_device(svo_world &w)
 
 // Persistent grid = the waves the kernel can keep resident (occupancy query), never more than tiles / tiles_per_wave.
 template <int MAXLV>
-static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, hipStream_t s)
+static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
 {
     auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES>;
     if (w->occupancy_blocks <= 0) {
@@ -114,10 +114,13 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, hi
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
         w->occupancy_blocks = prop.multiProcessorCount * per_cu;
+        if (const char *cap = std::getenv("SVO_GRID_WAVES_PER_CU")) { const int c = std::atoi(cap); if (c > 0) w->occupancy_blocks = prop.multiProcessorCount * std::min(c, per_cu); }     // experiments
     }
     const int64_t per_wave = tiles_per_wave > 1 ? tiles_per_wave : 1;
     const int64_t tiles = (int64_t)A.ntiles * (A.nframes > 0 ? A.nframes : 1);
-    const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, w->occupancy_blocks);
+    // launches the caller keeps in flight share the wave slots: 2/n each (include/svo.h, svo_trace_params.launches_in_flight)
+    const int64_t slots = in_flight >= 2 ? std::max<int64_t>(1, (int64_t)w->occupancy_blocks * 2 / in_flight) : w->occupancy_blocks;
+    const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, slots);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
 #ifdef SVO_RAW_HITS
     const int64_t records = A.n * (int64_t)(A.from_camera ? A.nframes : 1);
@@ -619,11 +622,11 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
         if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
         if (A.tile_cost) HIP_TRY(hipMemsetAsync(A.tile_cost, 0, (size_t)A.ntiles * (size_t)(A.from_camera ? A.nframes : 1) * 2 * sizeof(uint32_t), s));
         int rc;
-        const int tpw = prm ? prm->tiles_per_wave : 0;
-        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, tpw, s);
-        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, tpw, s);
-        else if (w->max_levels <= 16) rc = launch_stack<16>(w, A, tpw, s);
-        else rc = launch_stack<22>(w, A, tpw, s);
+        const int tpw = prm ? prm->tiles_per_wave : 0, nfl = prm ? prm->launches_in_flight : 0;
+        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, tpw, nfl, s);
+        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, tpw, nfl, s);
+        else if (w->max_levels <= 16) rc = launch_stack<16>(w, A, tpw, nfl, s);
+        else rc = launch_stack<22>(w, A, tpw, nfl, s);
         if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());

@@ -123,6 +123,7 @@ public:
         std::memset(&p, 0, sizeof p);
         p.shadow = shadow ? 1 : 0;
         p.tiles_per_wave = 4;                               // a rank's share is a small raster: keep the waves refilling
+        p.launches_in_flight = SLOTS;                       // calls alternate between SLOTS slots
         if (light_dir) std::memcpy(p.light_dir, light_dir, sizeof p.light_dir);
         std::vector<svo_camera> plain(cams.begin(), cams.end());
         const size_t share = (size_t)F * (size_t)S.nb * BAND * (size_t)S.width;            // records of one rank, all frames

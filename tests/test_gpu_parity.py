@@ -347,6 +347,18 @@ def test_tiles_per_wave_is_only_a_launch_shape(svo, worlds, tpw):
     assert buf.to_numpy(svo.HIT_DTYPE, 203 * 131).tobytes() == ref.tobytes()
 
 
+@pytest.mark.parametrize("nfl", [2, 4, 8, 1000])
+def test_launches_in_flight_is_only_a_launch_shape(svo, worlds, nfl):
+    """svo_trace_params.launches_in_flight shrinks the persistent grid to 2/n of the wave slots, never the records."""
+    W, O, lo, hi, _ = worlds["grid_2x1x2_d6"]
+    cam = svo.default_camera(2, 2, 128, 203, 131)
+    ref = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL).reshape(-1)
+    buf = svo.DeviceBuffer(203 * 131 * 32)
+    W.trace(cam, svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tiles_per_wave=4, launches_in_flight=nfl), (0, 0, 203, 131), buf.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    assert buf.to_numpy(svo.HIT_DTYPE, 203 * 131).tobytes() == ref.tobytes()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("nframes", [1, 3, 16])
 def test_frames_in_one_launch_equal_separate_traces(svo, worlds, kernel, nframes):
