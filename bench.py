@@ -417,7 +417,12 @@ def run(args):
             torch.cuda.synchronize()
             for f, ci in enumerate(group):
                 if not torch.equal(tmp[f], bufs[0][f]):
-                    raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
+                    # records flagged SVO_ERR_FLAG (a ray given up after 2^22 steps of the KERNEL's own counting) are outside the
+                    # cross-kernel contract: the two kernels count their steps differently near that bound (include/svo.h)
+                    a16, b16 = tmp[f].view(torch.int16).reshape(ih * iw, 16), bufs[0][f].view(torch.int16).reshape(ih * iw, 16)
+                    err = (a16[:, 9] < 0) | (b16[:, 9] < 0)                  # flags halfword, bit 15
+                    if not torch.equal(a16[~err], b16[~err]):
+                        raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
         del tmp, cnt
     else:
         for c in path:

@@ -185,7 +185,9 @@ enum {
     SVO_ERR_FLAG      = 1u << 15    /* runaway ray: given up after 2^22 march steps of the kernel's own counting (only rays that
                                        creep through all three nested loops of the reference get there; the stack kernel
                                        takes creeping stretches in closed form and finishes rays the literal kernel gives
-                                       up).  A primary ray is then recorded as a miss, a shadow ray as "traced, not occluded" */
+                                       up).  A primary ray is then recorded as a miss, a shadow ray as "traced, not occluded".  WHICH rays
+                                       get there depends on the kernel (each counts its own steps; the stack kernel also counts the passes a
+                                       lane waits for a vote): records carrying this flag are outside the cross-kernel equality */
 };
 #define SVO_CELL_NONE 0xFFu         /* hit a LEAF node, not a brick cell */
 
