@@ -155,3 +155,22 @@ def test_argument_validation_precedes_any_device_work(svo):
     assert tuple(P.point.position) == (50.0, 8.0, 65.0) and abs(P.spot.cos_phi - np.cos(np.radians(25.0))) < 1e-7
     assert P.materials[4].shininess == 10000.0 and tuple(P.materials[6].specular) == (1.0, 1.0, 1.0)
     assert P.eps == np.float32(1 / 8192) and P.near_plane == 0.125 and P.far_plane == 8192.0
+
+
+def test_stack_kernel_register_budget():
+    """The stack kernel is budgeted for six waves per SIMD (+9 %): hipcc must fit every instantiation
+    into 80 VGPRs, and the hand-written step (csrc/step_asm.hip.h, one asm statement) must be what it compiles - a change that
+    silently drops the kernel to five waves, or the build to the C++ step, fails here, on the CPU (hipcc cross-compiles)."""
+    import re
+    pkg = os.path.join(ROOT, "octree-raymarcher_amd")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                        "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage", "-S", "--cuda-device-only", "-o", "/tmp/svo_device_audit.s",
+                        os.path.join(pkg, "csrc", "device.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.findall(r"Function Name: (\S*k_trace_stack\S*).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S)
+    assert len(blocks) >= 4, "one instantiation per wide-level count"
+    for name, vgprs, occ in blocks:
+        assert int(vgprs) <= 80 and int(occ) >= 6, (name, vgprs, occ)
+    asm = open("/tmp/svo_device_audit.s").read()
+    body = asm[asm.index("k_trace_stackILi10E"):]
+    assert "v_cmpx_ge_f32" in body and ";;#ASMSTART" in body, "the hand-scheduled step is compiled in"
