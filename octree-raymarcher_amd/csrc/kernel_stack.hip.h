@@ -252,8 +252,21 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
     __shared__ uint32_t stk[MAXLV / 2 + 1][64];     // wide node index per wide level of the current path (level 0 is node 0)
     __shared__ float tile_ray[11][64];
+    // the chunk table (bmin, levels, wide offset, brick offset) of worlds of up to 64 chunks - the reference's default is 4x4x4 -
+    // staged in LDS: the chunk step then reads it there instead of waiting for a 32-byte global load per lane (the block runs
+    // in six of ten passes and a wave waits out the slowest lane's load each time)
+    __shared__ uint32_t chunk_tab[6][64];
     stk[0][threadIdx.x] = 0u;              // o, d, 1/d, world-entry t, output index (as int; -1 = no ray)
     const int lane = threadIdx.x;
+    const bool want_cost = A.tile_cost != nullptr;      // (one SGPR held; the blocks below must not re-read the kernel arguments for a feature that is off)
+    const int n_chunks = A.dimw * A.dimh * A.dimd;
+    const bool chunks_in_lds = n_chunks <= 64;
+    if (chunks_in_lds && lane < n_chunks) {
+        const DevWide ch = A.wchunks[lane];
+        chunk_tab[0][lane] = __float_as_uint(ch.bmin[0]); chunk_tab[1][lane] = __float_as_uint(ch.bmin[1]); chunk_tab[2][lane] = __float_as_uint(ch.bmin[2]);
+        chunk_tab[3][lane] = ch.levels; chunk_tab[4][lane] = ch.wide_off; chunk_tab[5][lane] = (uint32_t)ch.twig_off;
+    }
+    __syncthreads();
 #ifdef SVO_STACK_TIMING
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
@@ -470,13 +483,20 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     // descent compute a common prefix above this chunk's top level (keep < 0).
                     if (ci_new != ci) { valid = 0; pux = 0; puy = 0; puz = 0; }
                     ci = ci_new;
-                    const DevWide ch = A.wchunks[ci];
-                    clo = ld3(ch.bmin);
+                    uint32_t ch_levels, ch_wide, ch_twig;
+                    if (chunks_in_lds) {
+                        clo = mk(__uint_as_float(chunk_tab[0][ci]), __uint_as_float(chunk_tab[1][ci]), __uint_as_float(chunk_tab[2][ci]));
+                        ch_levels = chunk_tab[3][ci]; ch_wide = chunk_tab[4][ci]; ch_twig = chunk_tab[5][ci];
+                    } else {
+                        const DevWide ch = A.wchunks[ci];
+                        clo = ld3(ch.bmin);
+                        ch_levels = ch.levels; ch_wide = ch.wide_off; ch_twig = (uint32_t)ch.twig_off;
+                    }
                     miss = !inside(p, clo, clo + csize);
                     if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
-                        wide_b = ch.wide_off << 8;                   // 64 entries of 4 bytes per wide node
-                        twig_off = (uint32_t)ch.twig_off;
-                        levels = (int)ch.levels;
+                        wide_b = ch_wide << 8;                       // 64 entries of 4 bytes per wide node
+                        twig_off = ch_twig;
+                        levels = (int)ch_levels;
                         O = p; t = 0.0f; cnt = A.cap_tree;
                         Blo = clo;
                         res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);     // csize / 2^levels, exact
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
             if (miss) {
                 if (outk >= 0) store_miss(A.out, outk, 0);
-                note_tile_cost(outk, guard);
+                if (want_cost) note_tile_cost(outk, guard);
                 mode = M_DONE;                          // shadow miss: record already says "traced, lit"
             }
         }
@@ -837,7 +857,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && outk < 0) {
             store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
-            note_tile_cost(outk, guard);
+            if (want_cost) note_tile_cost(outk, guard);
             mode = M_DONE;
         }
         if (run_hit && mode == M_HIT) {
@@ -865,7 +885,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             const V3 n = face ? face_normal(point, vlo, vlo + vsize, beta) : cube_normal_pow2(point, vlo, vsize, eps);
             const uint32_t flags = SVO_HIT_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u) | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
             store_hit(A.out, outk, tw, n, material, flags, (uint32_t)ci, node, hitc);
-            note_tile_cost(outk, guard);
+            if (want_cost) note_tile_cost(outk, guard);
             mode = M_DONE;
             if (A.shadow) {                             // the lane becomes its own shadow ray
                 alpha = point; beta = sdir; g = sg;
