@@ -88,6 +88,11 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 #ifndef SVO_STEP_EXTRA
 #define SVO_STEP_EXTRA 3
 #endif
+// steps per statement while the inner repeat lasts (the drain of a launch: the wave is alone on its SIMD, every instruction of the
+// loop control around the statement costs it ~5 cycles)
+#ifndef SVO_DRAIN_STEPS
+#define SVO_DRAIN_STEPS 4
+#endif
 #ifndef SVO_STEP_LANES
 #define SVO_STEP_LANES 8
 #endif
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #endif
 #ifndef SVO_CXX_STEP
         // (step_asm.hip.h) the steps of this pass in one statement: 1 + fixed_steps at first, single steps while the inner repeat lasts
-        const int nsteps = pass == 0 ? 1 + fixed_steps : 1;
+        const int nsteps = pass == 0 ? 1 + fixed_steps : SVO_DRAIN_STEPS;
         march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
                         beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps);
         pass += nsteps - 1;
