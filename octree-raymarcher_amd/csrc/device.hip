@@ -587,8 +587,8 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
     // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
     // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
-    // (brick indices are 32-bit in the kernel: twig_off + payload)
-    const bool stack_ok = w->exact_geometry && w->max_levels <= (int)WIDE_MAX_LEVELS && w->wide_ok && w->twig_pool_cap < (1ull << 32);
+    // (brick indices are 32-bit in the kernel, and 8 * index is too: twig_off + payload < 2^29)
+    const bool stack_ok = w->exact_geometry && w->max_levels <= (int)WIDE_MAX_LEVELS && w->wide_ok && w->twig_pool_cap < (1ull << 29);     // (step_asm.hip.h: the mask pool is addressed by a 32-bit byte offset, 8 B per brick)
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
         if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 24 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
