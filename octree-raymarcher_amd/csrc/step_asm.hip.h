@@ -15,6 +15,7 @@
 //     lanes that leave evaluate nothing (kernel_stack.hip.h, "the one escape evaluation of the step");
 //   * no value is copied at a join: each outcome writes the lane state in place under its own mask.
 //
+//   * one load per lane and step: a BRANCH entry is not chased inside the step (see "a BRANCH entry" below);
 //   * latency: the PMC counters of the first hand-written version (22 % fewer instructions, the same wave cycles, waves 67 %
 //     of their time in s_waitcnt) showed what a wave-step really costs - its chain of dependent loads, the slowest lane's
 //     at that.  So the statement runs SEVERAL steps (the steps of one pass of the outer loop), the descent's first load is
@@ -177,39 +178,30 @@ __device__ __forceinline__ void march_steps_asm(
         "v_mov_b32 %[md], 2\n\t"
         "v_add_f32 %[tw], %[tw], %[q1]\n\t"
         "5:\n\t"
-        // ---- tree level, second half: the entry has arrived; further wide levels while it is a BRANCH
+        // ---- tree level, second half: the entry has arrived
         "s_andn2_b64 exec, %[sstay], %[stw]\n\t"
         "s_cbranch_execz 6f\n\t"
         "s_mov_b64 %[smar], exec\n\t"
+        "v_mov_b32 %[pux], %[ux]\n\t"                          // the descent cache is keyed to this cell either way
+        "v_mov_b32 %[puy], %[uy]\n\t"
+        "v_mov_b32 %[puz], %[uz]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        "3:\n\t"
-        "v_cmpx_gt_i32 vcc, -2.0, %[w]\n\t"                    // BRANCH entry (top bits 10): one more wide level
-        "s_cbranch_execz 4f\n\t"
+        // a BRANCH entry (top bits 10) means one more wide level.  The lane does not chase it inside this step - the whole wave would wait
+        // out a second dependent load for the 1.4 % of lane-steps that need one, in 40 % of its steps: it pushes the child node onto its
+        // descent cache, keys the cache to this cell, takes its cap decrement back and sits the step out; the next step recomputes the
+        // same p (t is unchanged), finds the cache valid down to the new level and loads the deeper entry as its FIRST load
+        "v_cmpx_gt_i32 vcc, -2.0, %[w]\n\t"
+        "s_mov_b64 %[sstay], exec\n\t"
         "v_and_b32 %[q3], 0x1ffffff, %[w]\n\t"
         "v_add_u32 %[val], 1, %[val]\n\t"
-        "v_sub_u32 %[q4], %[nw], %[val]\n\t"
+        "v_add_u32 %[cnt], 1, %[cnt]\n\t"
         "v_lshl_add_u32 %[q2], %[val], 8, %[lds]\n\t"
-        "v_lshl_add_u32 %[q4], %[q4], 1, -2\n\t"
         "ds_write_b32 %[q2], %[q3]\n\t"
-        "v_bfe_u32 %[q1], %[ux], %[q4], 2\n\t"
-        "v_bfe_u32 %[q5], %[uy], %[q4], 2\n\t"
-        "v_bfe_u32 %[q6], %[uz], %[q4], 2\n\t"
-        "v_lshl_or_b32 %[q1], %[q5], 2, %[q1]\n\t"
-        "v_lshl_or_b32 %[q1], %[q6], 4, %[q1]\n\t"
-        "v_lshl_or_b32 %[q1], %[q3], 6, %[q1]\n\t"
-        "v_lshl_add_u32 %[q1], %[q1], 2, %[wb]\n\t"
-        "global_load_dword %[w], %[q1], %[wide]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_branch 3b\n\t"
-        "4:\n\t"
-        "s_mov_b64 exec, %[smar]\n\t"
+        "s_andn2_b64 exec, %[smar], %[sstay]\n\t"              // the tree lanes whose entry is terminal
         "v_bfe_u32 %[plv], %[w], 25, 5\n\t"                    // the reference node's level
         "v_cmp_gt_u32_e64 %[sstay], 2.0, %[w]\n\t"             // EMPTY (type bits 00)
         "v_cmp_le_u32_e64 %[sent], -2.0, %[w]\n\t"             // TWIG  (type bits 11)
-        "v_mov_b32 %[pux], %[ux]\n\t"
         "v_sub_u32 %[q1], %[lev], %[plv]\n\t"
-        "v_mov_b32 %[puy], %[uy]\n\t"
-        "v_mov_b32 %[puz], %[uz]\n\t"
         "v_bfm_b32 %[low], %[q1], 0\n\t"                       // the node spans low + 1 cells
         "s_or_b64 %[sadv], %[sadv], %[sstay]\n\t"
         "v_cmpx_le_i32 vcc, 2.0, %[w]\n\t"                     // LEAF (type bits 01): hit, src/Traverse.cpp:93,160
