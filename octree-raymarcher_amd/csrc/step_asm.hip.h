@@ -32,6 +32,12 @@
 #pragma once
 #include "march.hip.h"
 
+#ifndef SVO_DESCEND_SHIFT
+#define SVO_DESCEND_SHIFT 2      // a wide level is taken inside the step when more than 1 / 2^this of the wave's tree lanes stand at a BRANCH entry
+#endif
+#define SVO_STR_(x) #x
+#define SVO_STR(x) SVO_STR_(x)
+
 namespace svo {
 
 struct StepUniform {            // wave-uniform inputs (SGPRs)
@@ -53,7 +59,7 @@ __device__ __forceinline__ void march_steps_asm(
     int ux, uy, uz, low;
     uint32_t w;
     unsigned long long sall, smar, stw, sstay, sadv, sent, q64;
-    int sctr;
+    int sctr, na, nb;
     asm volatile(
         "s_mov_b64 %[sall], exec\n\t"
         "s_mov_b32 %[sctr], %[nst]\n\t"
@@ -186,18 +192,42 @@ __device__ __forceinline__ void march_steps_asm(
         "v_mov_b32 %[puy], %[uy]\n\t"
         "v_mov_b32 %[puz], %[uz]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        // a BRANCH entry (top bits 10) means one more wide level.  The lane does not chase it inside this step - the whole wave would wait
-        // out a second dependent load for the 1.4 % of lane-steps that need one, in 40 % of its steps: it pushes the child node onto its
-        // descent cache, keys the cache to this cell, takes its cap decrement back and sits the step out; the next step recomputes the
-        // same p (t is unchanged), finds the cache valid down to the new level and loads the deeper entry as its FIRST load
+        // a BRANCH entry (top bits 10) means one more wide level.  A lane does not chase it inside this step when few lanes are in that
+        // position - the whole wave would wait out a second dependent load for the 1.4 % of lane-steps that need one, in 40 % of its
+        // steps: it pushes the child node onto its descent cache (already keyed to this cell), takes its cap decrement back and sits the
+        // step out; the next step recomputes the same p (t is unchanged), finds the cache valid down to the new level and loads the
+        // deeper entry as its FIRST load.  When more than a quarter of the wave's tree lanes stand at a BRANCH - fresh rays of one tile
+        // descending from the root together, deep trees - the level is taken inside the step, for all of them at once.
+        "3:\n\t"
         "v_cmpx_gt_i32 vcc, -2.0, %[w]\n\t"
-        "s_mov_b64 %[sstay], exec\n\t"
+        "s_cbranch_execz 4f\n\t"
+        "s_bcnt1_i32_b64 %[na], exec\n\t"
+        "s_bcnt1_i32_b64 %[nb], %[smar]\n\t"
         "v_and_b32 %[q3], 0x1ffffff, %[w]\n\t"
         "v_add_u32 %[val], 1, %[val]\n\t"
-        "v_add_u32 %[cnt], 1, %[cnt]\n\t"
+        "s_lshr_b32 %[nb], %[nb], " SVO_STR(SVO_DESCEND_SHIFT) "\n\t"
         "v_lshl_add_u32 %[q2], %[val], 8, %[lds]\n\t"
         "ds_write_b32 %[q2], %[q3]\n\t"
-        "s_andn2_b64 exec, %[smar], %[sstay]\n\t"              // the tree lanes whose entry is terminal
+        "s_cmp_gt_u32 %[na], %[nb]\n\t"
+        "s_cbranch_scc0 35f\n\t"
+        "v_sub_u32 %[q4], %[nw], %[val]\n\t"                   // many: the next wide level now
+        "v_lshl_add_u32 %[q4], %[q4], 1, -2\n\t"
+        "v_bfe_u32 %[q1], %[ux], %[q4], 2\n\t"
+        "v_bfe_u32 %[q5], %[uy], %[q4], 2\n\t"
+        "v_bfe_u32 %[q6], %[uz], %[q4], 2\n\t"
+        "v_lshl_or_b32 %[q1], %[q5], 2, %[q1]\n\t"
+        "v_lshl_or_b32 %[q1], %[q6], 4, %[q1]\n\t"
+        "v_lshl_or_b32 %[q1], %[q3], 6, %[q1]\n\t"
+        "v_lshl_add_u32 %[q1], %[q1], 2, %[wb]\n\t"
+        "global_load_dword %[w], %[q1], %[wide]\n\t"
+        "s_mov_b64 exec, %[smar]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_branch 3b\n\t"
+        "35:\n\t"
+        "v_add_u32 %[cnt], 1, %[cnt]\n\t"                      // few: these lanes sit the step out
+        "s_andn2_b64 %[smar], %[smar], exec\n\t"
+        "4:\n\t"
+        "s_mov_b64 exec, %[smar]\n\t"                          // the tree lanes whose entry is terminal
         "v_bfe_u32 %[plv], %[w], 25, 5\n\t"                    // the reference node's level
         "v_cmp_gt_u32_e64 %[sstay], 2.0, %[w]\n\t"             // EMPTY (type bits 00)
         "v_cmp_le_u32_e64 %[sent], -2.0, %[w]\n\t"             // TWIG  (type bits 11)
@@ -333,7 +363,7 @@ __device__ __forceinline__ void march_steps_asm(
           [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [ux] "=&v"(ux), [uy] "=&v"(uy), [uz] "=&v"(uz),
           [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [q4] "=&v"(q4), [q5] "=&v"(q5), [q6] "=&v"(q6), [q7] "=&v"(q7),
           [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [low] "=&v"(low), [w] "=&v"(w), [q64] "=&v"(q64),
-          [sall] "=&s"(sall), [smar] "=&s"(smar), [stw] "=&s"(stw), [sstay] "=&s"(sstay), [sadv] "=&s"(sadv), [sent] "=&s"(sent), [sctr] "=&s"(sctr)
+          [sall] "=&s"(sall), [smar] "=&s"(smar), [stw] "=&s"(stw), [sstay] "=&s"(sstay), [sadv] "=&s"(sadv), [sent] "=&s"(sent), [sctr] "=&s"(sctr), [na] "=&s"(na), [nb] "=&s"(nb)
         : [bx] "v"(beta.x), [by] "v"(beta.y), [bz] "v"(beta.z), [gx] "v"(g.x), [gy] "v"(g.y), [gz] "v"(g.z),
           [clx] "v"(clo.x), [cly] "v"(clo.y), [clz] "v"(clo.z), [ax] "v"(alpha.x), [ay] "v"(alpha.y), [az] "v"(alpha.z),
           [lev] "v"(levels), [nw] "v"(nw), [rtr] "v"(res_tree), [wb] "v"(wide_b), [tof] "v"(twig_off), [lds] "v"(lds_lane),
