@@ -18,6 +18,8 @@
  *                           src/Main.cpp:190-222; stereo / split-screen views; a pipelined renderer's next frames)
  *   svo_trace_rows(_frames) <- the same over the interleaved row bands of one rank (multi-GPU partition)
  *   svo_trace_rays       <- chunkmarch over a ray list             src/Traverse.cpp:127-171
+ *   svo_tile_order       <- (no counterpart: the GL rasteriser schedules fragments itself) longest-first tile order of the
+ *                           next World::draw from the previous one's per-tile step counts
  *   svo_world_destroy    <- World::deinit                          src/World.cpp:129-151
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
  *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
