@@ -19,7 +19,9 @@
 //    = two reference levels per dependent load).  The wide node of every wide level of the current path is cached in
 //    a per-lane LDS column ([level][lane]: bank = lane, conflict-free); the next step restarts at the deepest level
 //    whose coordinate prefix is unchanged - and keeps the cache across rays of the same chunk (a shadow ray starts
-//    where its primary ray ended): ~1.4 dependent loads per tree step instead of one per level.
+//    where its primary ray ended).  ONE dependent load per lane and step: a lane whose entry is a BRANCH pushes the child
+//    onto its cache and sits the step out (step_asm.hip.h) - the wave never waits for a second level, unless a quarter of
+//    its tree lanes need one.
 //  * Bricks are tested against a 64-bit occupancy mask held in registers (one 8-byte load per
 //    brick visit); the 128-byte brick line is touched only to fetch the hit material.
 //  * Ray generation (camera ray, 1/dir, world-entry distance: ~10 IEEE divisions) is done once per
@@ -35,8 +37,12 @@
 //    launch's last waves are alone on their SIMD, bound by their own instruction stream.  Scalar instructions and
 //    branches cost a SIMD what vector instructions do (scripts/microbench/valu_issue.hip): the step avoids them
 //    where a select or an unconditional LDS read does the same.
+//  * The step itself is one hand-scheduled asm statement that runs the steps of a pass (step_asm.hip.h; the C++ step below
+//    is the readable statement of the same algorithm, built with -DSVO_CXX_STEP): what a wave-step costs is its chain of
+//    dependent loads and the instructions between them, and that chain is what the statement is arranged around.
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
-//    reference's own expressions instead of being held): 96 VGPRs, 5 waves per SIMD.
+//    reference's own expressions instead of being held): 80 VGPRs, 6 waves per SIMD, no spill inside the pass loop.
+//  * The chunk table of worlds of up to 64 chunks sits in LDS: the chunk step waits for no global load.
 //
 // All float arithmetic that decides t is evaluated exactly as in the reference; only loads and
 // integer bookkeeping differ.  Divisions by powers of two (chunk edge, node edge) are written as
