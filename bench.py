@@ -256,17 +256,19 @@ def run(args):
     gw, gh, gd, depth, iw, ih, shadow = WORKLOADS[args.workload]
     kernel = {"auto": svo.KERNEL_AUTO, "literal": svo.KERNEL_LITERAL, "stack": svo.KERNEL_STACK}[args.kernel]
 
-    # ---- world: generated by every rank for itself, on its own GPU (noise, mips and grow() as kernels, pools left in
-    # HBM: deterministic -> identical on every rank).  Only the water fill's node edits run on the host; the ranks of
-    # one node share its cores, each takes its share of the threads.
+    # ---- world: generated by every rank for itself, on its own GPU (noise, mips, grow() and the water fill as kernels,
+    # pools left in HBM: deterministic -> identical on every rank).  Generated twice: the first call of a process also
+    # pays the HIP runtime's first-use costs (code object load, first allocations), the second is the builder alone.
     local_ranks = int(os.environ.get("LOCAL_WORLD_SIZE", str(world_size)))
     gen_threads = max(1, (os.cpu_count() or 1) // max(1, local_ranks))
+    gen_kw = svo.c5_scene()["generate"] if args.workload.startswith("c5_") else {}
     t0 = time.time()
-    if args.workload.startswith("c5_"):
-        world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **svo.c5_scene()["generate"])
-    else:
-        world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank)
+    world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **gen_kw)
     t_gen = time.time() - t0
+    world.destroy()
+    t0 = time.time()
+    world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **gen_kw)
+    t_gen_warm = time.time() - t0
     t0 = time.time()
     world.upload(local_rank)                       # already resident where it was built: a no-op
     t_up = time.time() - t0
@@ -600,7 +602,8 @@ def run(args):
                 "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "ranks_seen": ranks_seen, "devices": devices,
                 "launcher": "self-spawned" if os.environ.get("SVO_BENCH_SPAWNED") else ("external" if "WORLD_SIZE" in os.environ else "single process"),
-                "world_generate_s": round(t_gen, 2), "world_generate": "on the rank's GPU, pools left in HBM", "world_generate_threads": gen_threads, "world_upload_s": round(t_up, 3),
+                "world_generate_s": round(t_gen, 3), "world_generate_warm_s": round(t_gen_warm, 3),
+                "world_generate": "on the rank's GPU (noise, mips, grow, water fill), pools left in HBM; _s = first call of the process, _warm_s = second", "world_generate_threads": gen_threads, "world_upload_s": round(t_up, 3),
             },
         }
         if single:

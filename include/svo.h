@@ -110,8 +110,8 @@ typedef struct svo_terrain_params {
     uint32_t coarse_depth;
     float    refine_min[3];
     float    refine_max[3];
-    /* 0 = generate on host threads; k > 0 = generate on HIP device k-1 (noise, mips and the level-synchronous
-     * BFS as kernels, bit-identical pools; only the water fill stays on the host). */
+    /* 0 = generate on host threads; k > 0 = generate on HIP device k-1 (noise, mips, the level-synchronous BFS and
+     * the water fill as kernels, bit-identical pools that never visit the host). */
     int32_t  build_device_plus1;
 } svo_terrain_params;
 

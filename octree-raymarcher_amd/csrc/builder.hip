@@ -9,7 +9,8 @@
 //        exclusive scans of the BRANCH and TWIG flags (rocPRIM) == the reference queue's append order
 //        k_emit     (node words, the 8 children of every BRANCH into the next frontier, :155-174)
 //        k_bricks_rows (one thread per brick z-row: 4 column lookups, 16 cells, one 32-byte store, :122-154)
-// The water fill (Ocroot::build) appends blocks in depth-first order and stays on the host (74 ms at depth 12).
+//   Ocroot::build (the water plane)   src/Octree.cpp:320-436         -> DeviceFiller below: the depth-first fill as three
+//        level-synchronous sweeps (classify top-down, count bottom-up, number top-down); the node words never visit the host
 //
 // Layout on the device: the pyramid is the same flat array per bound as on the host (level lv at (4^lv-1)/3,
 // row-major): mip kernels read/write whole rows coalesced; frontier entries are 16 B {x, y, z, slot}.
@@ -158,9 +159,10 @@ struct GrowArgs {
     float rmin[3], rmax[3];     // refine box
 };
 
-// type of every frontier node (src/Octree.cpp:105-121) + flags for the scans
+// type of every frontier node (src/Octree.cpp:105-121) + its flags for the scan (BRANCH in the low half, TWIG in the high half of
+// one 64-bit word: one scan ranks both) and the level's totals
 __global__ __launch_bounds__(256) void k_classify(const Cell *frontier, uint32_t n, GrowArgs G, DevPyramid P,
-                                                  uint32_t *word, uint32_t *is_branch, uint32_t *is_twig)
+                                                  uint32_t *word, unsigned long long *flags, uint32_t *totals /* [0] BRANCH, [1] TWIG */)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -181,14 +183,15 @@ __global__ __launch_bounds__(256) void k_classify(const Cell *frontier, uint32_t
         else { w = node_make(BRANCH, 0); br = 1; }
     }
     word[i] = w;
-    is_branch[i] = br;
-    is_twig[i] = tw;
+    flags[i] = (unsigned long long)br | ((unsigned long long)tw << 32);
+    if (br) atomicAdd(&totals[0], 1u);
+    if (tw) atomicAdd(&totals[1], 1u);
 }
 
 // node words; children of every BRANCH appended to the next frontier in parent order (== FIFO queue order);
 // brick jobs listed in TWIG order
 __global__ __launch_bounds__(256) void k_emit(const Cell *frontier, uint32_t n, float half, const uint32_t *word,
-                                              const uint32_t *branch_rank, const uint32_t *twig_rank,
+                                              const unsigned long long *rank /* BRANCH rank | TWIG rank << 32 */,
                                               uint32_t trees, uint32_t twigs, uint32_t *tree, Cell *next, Cell *brick_jobs)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -197,19 +200,21 @@ __global__ __launch_bounds__(256) void k_emit(const Cell *frontier, uint32_t n, 
     uint32_t w = word[i];
     const uint32_t type = node_type(w);
     if (type == BRANCH) {
-        const uint32_t first = trees + 8 * branch_rank[i];
+        const uint32_t branch_rank = (uint32_t)rank[i];
+        const uint32_t first = trees + 8 * branch_rank;
         w = node_make(BRANCH, first);
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c) {
             const float ox = (c & 1) ? 1.0f : 0.0f, oy = (c & 2) ? 1.0f : 0.0f, oz = (c & 4) ? 1.0f : 0.0f;
             Cell ch; ch.x = e.x + ox * half; ch.y = e.y + oy * half; ch.z = e.z + oz * half; ch.slot = first + c;
-            next[8 * (uint64_t)branch_rank[i] + c] = ch;
+            next[8 * (uint64_t)branch_rank + c] = ch;
         }
     } else if (type == TWIG) {
-        const uint32_t brick = twigs + twig_rank[i];
+        const uint32_t twig_rank = (uint32_t)(rank[i] >> 32);
+        const uint32_t brick = twigs + twig_rank;
         w = node_make(TWIG, brick);
         Cell job = e; job.slot = brick;
-        brick_jobs[twig_rank[i]] = job;
+        brick_jobs[twig_rank] = job;
     }
     tree[e.slot] = w;
 }
@@ -294,83 +299,132 @@ struct DevicePyramidBuilder {
     }
 };
 
-struct DeviceGrower {
-    DevBuf<Cell> frontier, next, jobs;
-    DevBuf<uint32_t> word, is_branch, is_twig, branch_rank, twig_rank, tree;
-    DevBuf<uint16_t> twig;
-    DevBuf<unsigned char> scan_tmp;
+// ---- Ocroot::build on the device (src/Octree.cpp:320-436; the host restatement is terrain.cpp's Filler) ------------------
+// The reference fills depth-first in child-slot order and APPENDS as it goes: an EMPTY node the region cuts becomes a BRANCH
+// whose 8-block lands at the pool's tail (a "split"), or - at the brick level - a TWIG whose brick lands at the brick pool's
+// tail.  So the index a new block / brick gets is the number of splits / new bricks that precede it in depth-first preorder.
+// Three level-synchronous sweeps over the nodes the region touches give exactly that:
+//   A (top-down)   k_fill_classify: what the visit does at each node (its action), the 8 children of every node the visit
+//                  descends into appended to the next level's list (any order: the lists only link parents to children)
+//   B (bottom-up)  k_fill_count: splits / new bricks in each node's subtree
+//   C (top-down)   k_fill_number: preorder prefix of those counts = each event's index; node words written, new blocks
+//                  initialised EMPTY, brick edits listed for k_brick_fill
+// A node the fill creates has no slot until sweep C: its list entry carries FILL_VIRTUAL until its parent numbers it.
+enum FillAction : uint32_t { FILL_NONE = 0, FILL_MAKE_LEAF, FILL_NEW_BRICK, FILL_SPLIT, FILL_BRICK, FILL_DESCEND };
+constexpr uint32_t FILL_VIRTUAL = 0xFFFFFFFFu;
 
-    // The node words go to the host copy (the water fill edits them there); the bricks stay in HBM: *bricks_dev receives the
-    // device array (caller owns it, hipFree), c.twigs_on_device their number.
-    int grow(ChunkPools &c, const float position[3], float size, uint32_t depth, const DevPyramid &P, const TerrainParams &tp, hipStream_t s,
-             uint16_t **bricks_dev)
-    {
-        c.position[0] = position[0]; c.position[1] = position[1]; c.position[2] = position[2];
-        c.size = size; c.depth = depth;
-        c.tree_capacity = 16; c.twig_capacity = 16;
-        uint64_t trees = 1, twigs = 0;
-        int rc;
-        if ((rc = frontier.reserve(1, false, s)) != SVO_OK || (rc = tree.reserve(1024, false, s)) != SVO_OK) return rc;
-        const Cell root = { position[0], position[1], position[2], 0u };
-        BUILD_TRY(hipMemcpyAsync(frontier.p, &root, sizeof root, hipMemcpyHostToDevice, s));
-        uint32_t n = 1;
-        float edge = size;
-        GrowArgs G{};
-        G.px = position[0]; G.py = position[1]; G.pz = position[2]; G.size = size; G.depth = depth;
-        const bool coarse = tp.coarse_depth >= TWIG_LEVELS && tp.coarse_depth < depth;
-        G.coarse_depth = coarse ? tp.coarse_depth : 0;
-        for (int a = 0; a < 3; ++a) { G.rmin[a] = tp.refine_min[a]; G.rmax[a] = tp.refine_max[a]; }
-
-        for (uint32_t level = 0; n > 0; ++level) {
-            const float half = edge / 2;
-            G.level = level; G.edge = edge;
-            if ((rc = word.reserve(n, false, s)) != SVO_OK || (rc = is_branch.reserve(n, false, s)) != SVO_OK || (rc = is_twig.reserve(n, false, s)) != SVO_OK ||
-                (rc = branch_rank.reserve(n, false, s)) != SVO_OK || (rc = twig_rank.reserve(n, false, s)) != SVO_OK) return rc;
-            hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256)), dim3(256), 0, s, frontier.p, n, G, P, word.p, is_branch.p, is_twig.p);
-            size_t need = 0;
-            BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, is_branch.p, branch_rank.p, (int)n, s));
-            if ((rc = scan_tmp.reserve(need + 16, false, s)) != SVO_OK) return rc;
-            BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, need, is_branch.p, branch_rank.p, (int)n, s));
-            BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, need, is_twig.p, twig_rank.p, (int)n, s));
-            uint32_t tail[4];       // last rank + last flag of both scans
-            BUILD_TRY(hipMemcpyAsync(&tail[0], branch_rank.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-            BUILD_TRY(hipMemcpyAsync(&tail[1], is_branch.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-            BUILD_TRY(hipMemcpyAsync(&tail[2], twig_rank.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-            BUILD_TRY(hipMemcpyAsync(&tail[3], is_twig.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
-            BUILD_TRY(hipStreamSynchronize(s));
-            const uint64_t nb = (uint64_t)tail[0] + tail[1], nt = (uint64_t)tail[2] + tail[3];
-            if (trees + 8 * nb >= (1ull << 30) || twigs + nt >= (1ull << 30)) { set_error("device builder: chunk exceeds the 30-bit node offset"); return SVO_ERR_UNSUPPORTED; }
-            if ((rc = tree.reserve(trees + 8 * nb, true, s)) != SVO_OK || (rc = twig.reserve((twigs + nt) * TWIG_WORDS, true, s)) != SVO_OK ||
-                (rc = next.reserve(std::max<uint64_t>(8 * nb, 1), false, s)) != SVO_OK || (rc = jobs.reserve(std::max<uint64_t>(nt, 1), false, s)) != SVO_OK) return rc;
-            hipLaunchKernelGGL(k_emit, dim3(blocks_for(n, 256)), dim3(256), 0, s, frontier.p, n, half, word.p, branch_rank.p, twig_rank.p,
-                               (uint32_t)trees, (uint32_t)twigs, tree.p, next.p, jobs.p);
-            if (nt) hipLaunchKernelGGL(k_bricks_rows, dim3(blocks_for(nt * 4, 256)), dim3(256), 0, s, jobs.p, (uint32_t)nt, G, P, twig.p);
-            BUILD_TRY(hipGetLastError());
-            // capacity bookkeeping exactly as the host builder (src/Octree.cpp:149-150,160-161)
-            if (nb) while (trees + 8 * nb >= c.tree_capacity) c.tree_capacity *= 2;
-            while (twigs + nt > c.twig_capacity) c.twig_capacity *= 2;
-            trees += 8 * nb; twigs += nt;
-            std::swap(frontier.p, next.p); std::swap(frontier.cap, next.cap);
-            n = (uint32_t)(8 * nb);
-            edge = half;
-        }
-        c.tree.resize(trees);
-        c.twig.clear();
-        BUILD_TRY(hipMemcpyAsync(c.tree.data(), tree.p, trees * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        BUILD_TRY(hipStreamSynchronize(s));
-        c.twigs_on_device = twigs;
-        *bricks_dev = twig.p;                       // hand the brick array over; the next chunk gets a fresh one
-        twig.p = nullptr; twig.cap = 0;
-        return SVO_OK;
-    }
+struct FillArgs {
+    float rlo[3], rhi[3];       // the region (closed box)
+    float edge;                 // node edge at this level
+    uint32_t level, maxlevel;   // maxlevel = depth - TWIG_LEVELS: EMPTY nodes there become bricks
+    uint32_t material;
 };
 
-static int positive_mod_b(int n, int m) { return (m + (n % m)) % m; }
+// act[i] = action | kids << 8 (kids = index of the node's child block in the next level's list)
+__global__ __launch_bounds__(256) void k_fill_classify(const Cell *cells, uint32_t n, FillArgs F, const uint32_t *tree,
+                                                       uint32_t *act, Cell *next, uint32_t *counters /* [0] child blocks, [1] brick edits */)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Cell e = cells[i];
+    const float hx = e.x + F.edge, hy = e.y + F.edge, hz = e.z + F.edge;
+    uint32_t a = FILL_NONE, word = node_make(EMPTY, 0);
+    // cubesIntersect on closed boxes (src/Traverse.cpp:173-178), the host Filler's expressions
+    const bool touch = hx >= F.rlo[0] && hy >= F.rlo[1] && hz >= F.rlo[2] && F.rhi[0] >= e.x && F.rhi[1] >= e.y && F.rhi[2] >= e.z;
+    if (touch) {
+        if (e.slot != FILL_VIRTUAL) word = tree[e.slot];
+        switch (node_type(word)) {
+        case LEAF: break;
+        case EMPTY: {
+            // cubeIsInside (src/Traverse.cpp:180-185)
+            const bool inside = e.x >= F.rlo[0] && e.y >= F.rlo[1] && e.z >= F.rlo[2] && F.rhi[0] >= hx && F.rhi[1] >= hy && F.rhi[2] >= hz;
+            a = inside ? FILL_MAKE_LEAF : (F.level == F.maxlevel ? FILL_NEW_BRICK : FILL_SPLIT);
+            break;
+        }
+        case TWIG: a = FILL_BRICK; break;
+        default: a = FILL_DESCEND; break;
+        }
+    }
+    uint32_t kids = 0;
+    if (a == FILL_SPLIT || a == FILL_DESCEND) {
+        kids = atomicAdd(&counters[0], 1u);
+        const float half = F.edge * 0.5f;
+        const uint32_t first = node_offset(word);
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const float ox = (c & 1) ? 1.0f : 0.0f, oy = (c & 2) ? 1.0f : 0.0f, oz = (c & 4) ? 1.0f : 0.0f;
+            Cell ch; ch.x = e.x + ox * half; ch.y = e.y + oy * half; ch.z = e.z + oz * half;
+            ch.slot = a == FILL_DESCEND ? first + c : FILL_VIRTUAL;
+            next[8 * (uint64_t)kids + c] = ch;
+        }
+    }
+    if (a == FILL_NEW_BRICK || a == FILL_BRICK) atomicAdd(&counters[1], 1u);
+    act[i] = a | (kids << 8);
+}
 
-// Ocroot::build on bricks that live in the pool (fill_box_plan recorded which): cell empty and its voxel box touches the
-// region -> material (src/Octree.cpp:395-410; cubesIntersect on closed boxes, the host Filler's expressions).
+// cnt[i] = {splits, new bricks} in the subtree of node i, itself included
+__global__ __launch_bounds__(256) void k_fill_count(const uint32_t *act, uint32_t n, const uint2 *cnt_next, uint2 *cnt)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = act[i] & 255u, kids = act[i] >> 8;
+    uint2 v = make_uint2(a == FILL_SPLIT ? 1u : 0u, a == FILL_NEW_BRICK ? 1u : 0u);
+    if (a == FILL_SPLIT || a == FILL_DESCEND) {
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) { const uint2 k = cnt_next[8 * (uint64_t)kids + c]; v.x += k.x; v.y += k.y; }
+    }
+    cnt[i] = v;
+}
+
 struct DevBrickOp { uint64_t brick; float x, y, z, voxel; };
-static_assert(sizeof(DevBrickOp) == sizeof(BrickOp), "BrickOp is uploaded as it is");
+
+// On entry cnt[i] = {splits, new bricks} that precede node i's own events in preorder (the root: 0, 0); the node's children
+// get theirs (their subtree counts are replaced by the running prefix), new nodes get their slots, node words are written.
+__global__ __launch_bounds__(256) void k_fill_number(Cell *cells, uint32_t n, FillArgs F, const uint32_t *act, const uint2 *cnt,
+                                                     Cell *next, uint2 *cnt_next, uint32_t trees0, uint32_t twigs0,
+                                                     uint32_t *tree, DevBrickOp *ops, uint32_t *op_cursor)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = act[i] & 255u, kids = act[i] >> 8;
+    if (a == FILL_NONE) return;
+    const Cell e = cells[i];
+    const uint2 base = cnt[i];
+    switch (a) {
+    case FILL_MAKE_LEAF:
+        tree[e.slot] = node_make(LEAF, F.material);
+        break;
+    case FILL_NEW_BRICK:
+    case FILL_BRICK: {
+        uint32_t brick;
+        if (a == FILL_NEW_BRICK) { brick = twigs0 + base.y; tree[e.slot] = node_make(TWIG, brick); }
+        else brick = node_offset(tree[e.slot]);
+        DevBrickOp op; op.brick = brick; op.x = e.x; op.y = e.y; op.z = e.z; op.voxel = F.edge / (float)(1 << TWIG_LEVELS);
+        ops[atomicAdd(op_cursor, 1u)] = op;
+        break;
+    }
+    default: {
+        uint2 run = base;
+        uint32_t first = 0;
+        if (a == FILL_SPLIT) {
+            first = trees0 + 8u * base.x;
+            tree[e.slot] = node_make(BRANCH, first);
+            run.x += 1;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) {
+            const uint64_t k = 8 * (uint64_t)kids + c;
+            if (a == FILL_SPLIT) { tree[first + c] = node_make(EMPTY, 0); next[k].slot = first + c; }
+            const uint2 sub = cnt_next[k];
+            cnt_next[k] = run;
+            run.x += sub.x; run.y += sub.y;
+        }
+    }
+    }
+}
+
+// Ocroot::build on bricks that live in the pool: cell empty and its voxel box touches the region -> material
+// (src/Octree.cpp:395-410; cubesIntersect on closed boxes, the host Filler's expressions).
 __global__ __launch_bounds__(256) void k_brick_fill(uint16_t *twig, const DevBrickOp *ops, uint32_t n, uint64_t first_brick,
                                                     float rlx, float rly, float rlz, float rhx, float rhy, float rhz, uint32_t material)
 {
@@ -386,10 +440,175 @@ __global__ __launch_bounds__(256) void k_brick_fill(uint16_t *twig, const DevBri
     if (touch) *p = (uint16_t)material;
 }
 
-// World::init on the device, pools left in HBM: noise, mips and grow() as kernels (above); the node words visit the host
-// for the water fill (Ocroot::build appends depth-first: order-dependent, 25 MB per depth-12 chunk), the bricks - 10x the
-// bytes - never leave the device: the fill's brick edits are applied in place by k_brick_fill.  The pools are packed
-// exactly as svo_world_upload packs them; the world is uploaded to `device` when this returns.
+struct DeviceFiller {
+    struct Level { DevBuf<Cell> cells; DevBuf<uint32_t> act; DevBuf<uint2> cnt; uint32_t n = 0; };
+    std::vector<Level> lv;
+    DevBuf<uint32_t> counters;      // [2 * level + {0, 1}] of sweep A, [64] the op cursor of sweep C
+    DevBuf<DevBrickOp> ops;
+    uint32_t *h_counters = nullptr; // pinned
+    ~DeviceFiller() { if (h_counters) (void)hipHostFree(h_counters); }
+
+    // The fill of region [lo, hi] with `material` applied to the chunk grow() left in `tree` (trees nodes) and `twig` (twigs
+    // bricks); both buffers grow as needed, c's counts and capacities follow the reference's bookkeeping.
+    int fill(ChunkPools &c, const float lo[3], const float hi[3], uint32_t material, DevBuf<uint32_t> &tree, uint64_t &trees,
+             DevBuf<uint16_t> &twig, uint64_t &twigs, hipStream_t s)
+    {
+        int rc;
+        const uint32_t maxlevel = c.depth - TWIG_LEVELS;
+        if (lv.size() < maxlevel + 2) lv.resize(maxlevel + 2);
+        if ((rc = counters.reserve(80, false, s)) != SVO_OK) return rc;
+        if (!h_counters) BUILD_TRY(hipHostMalloc((void **)&h_counters, 80 * sizeof(uint32_t)));
+        BUILD_TRY(hipMemsetAsync(counters.p, 0, 80 * sizeof(uint32_t), s));
+        FillArgs F{};
+        for (int a = 0; a < 3; ++a) { F.rlo[a] = lo[a]; F.rhi[a] = hi[a]; }
+        F.maxlevel = maxlevel; F.material = material;
+        // sweep A
+        if ((rc = lv[0].cells.reserve(1, false, s)) != SVO_OK) return rc;
+        const Cell root = { c.position[0], c.position[1], c.position[2], 0u };
+        BUILD_TRY(hipMemcpyAsync(lv[0].cells.p, &root, sizeof root, hipMemcpyHostToDevice, s));
+        lv[0].n = 1;
+        float edge = c.size;
+        uint32_t last = 0, brick_edits = 0;
+        std::vector<float> edges(maxlevel + 1);
+        for (uint32_t level = 0; level <= maxlevel; ++level) {
+            Level &L = lv[level], &N = lv[level + 1];
+            const uint32_t n = L.n;
+            edges[level] = edge;
+            last = level;
+            if ((rc = L.act.reserve(n, false, s)) != SVO_OK || (rc = L.cnt.reserve(n, false, s)) != SVO_OK ||
+                (rc = N.cells.reserve((uint64_t)n * 8, false, s)) != SVO_OK) return rc;
+            F.level = level; F.edge = edge;
+            hipLaunchKernelGGL(k_fill_classify, dim3(blocks_for(n, 256)), dim3(256), 0, s, L.cells.p, n, F, tree.p, L.act.p, N.cells.p, counters.p + 2 * level);
+            BUILD_TRY(hipGetLastError());
+            BUILD_TRY(hipMemcpyAsync(h_counters, counters.p + 2 * level, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            BUILD_TRY(hipStreamSynchronize(s));
+            brick_edits += h_counters[1];
+            if ((uint64_t)h_counters[0] * 8 >= (1ull << 31)) { set_error("device builder: the fill's frontier exceeds 2^31 nodes"); return SVO_ERR_UNSUPPORTED; }
+            N.n = h_counters[0] * 8u;
+            edge = edge * 0.5f;
+            if (N.n == 0) break;
+            // a node at maxlevel is never split and grow() puts no BRANCH there
+            if (level == maxlevel) { set_error("device builder: BRANCH below level depth-2"); return SVO_ERR_MALFORMED_TREE; }
+        }
+        // sweep B
+        for (int level = (int)last; level >= 0; --level) {
+            Level &L = lv[(size_t)level], &N = lv[(size_t)level + 1];
+            hipLaunchKernelGGL(k_fill_count, dim3(blocks_for(L.n, 256)), dim3(256), 0, s, L.act.p, L.n, N.cnt.p, L.cnt.p);
+        }
+        BUILD_TRY(hipGetLastError());
+        uint2 total;
+        BUILD_TRY(hipMemcpyAsync(h_counters, lv[0].cnt.p, sizeof(uint2), hipMemcpyDeviceToHost, s));
+        BUILD_TRY(hipStreamSynchronize(s));
+        total.x = h_counters[0]; total.y = h_counters[1];
+        const uint64_t trees1 = trees + 8ull * total.x, twigs1 = twigs + total.y;
+        if (trees1 >= (1ull << 30) || twigs1 >= (1ull << 30)) { set_error("device builder: chunk exceeds the 30-bit node offset"); return SVO_ERR_UNSUPPORTED; }
+        if ((rc = tree.reserve(trees1, true, s)) != SVO_OK || (rc = twig.reserve(std::max<uint64_t>(twigs1, 1) * TWIG_WORDS, true, s)) != SVO_OK ||
+            (rc = ops.reserve(std::max<uint32_t>(brick_edits, 1u), false, s)) != SVO_OK) return rc;
+        if (total.y) BUILD_TRY(hipMemsetAsync(twig.p + twigs * TWIG_WORDS, 0, (size_t)total.y * TWIG_WORDS * sizeof(uint16_t), s));
+        BUILD_TRY(hipMemsetAsync(lv[0].cnt.p, 0, sizeof(uint2), s));
+        // sweep C
+        for (uint32_t level = 0; level <= last; ++level) {
+            Level &L = lv[level], &N = lv[level + 1];
+            F.level = level; F.edge = edges[level];
+            hipLaunchKernelGGL(k_fill_number, dim3(blocks_for(L.n, 256)), dim3(256), 0, s, L.cells.p, L.n, F, L.act.p, L.cnt.p, N.cells.p, N.cnt.p,
+                               (uint32_t)trees, (uint32_t)twigs, tree.p, ops.p, counters.p + 64);
+        }
+        if (brick_edits)
+            hipLaunchKernelGGL(k_brick_fill, dim3(blocks_for((uint64_t)brick_edits * 64, 256)), dim3(256), 0, s, twig.p, ops.p, brick_edits, (uint64_t)0,
+                               F.rlo[0], F.rlo[1], F.rlo[2], F.rhi[0], F.rhi[1], F.rhi[2], material);
+        BUILD_TRY(hipGetLastError());
+        // capacity bookkeeping of the reference's appends (src/Octree.cpp:349-351,365-368; terrain.cpp's Filler)
+        if (total.x) while (trees1 >= c.tree_capacity) c.tree_capacity *= 2;
+        while (twigs1 > c.twig_capacity) c.twig_capacity *= 2;
+        trees = trees1; twigs = twigs1;
+        return SVO_OK;
+    }
+};
+
+struct DeviceGrower {
+    DevBuf<Cell> frontier, next, jobs;
+    DevBuf<uint32_t> word, tree, totals;
+    DevBuf<unsigned long long> flags, rank;
+    DevBuf<uint16_t> twig;
+    DevBuf<unsigned char> scan_tmp;
+    uint32_t *h_totals = nullptr;               // pinned
+    ~DeviceGrower() { if (h_totals) (void)hipHostFree(h_totals); }
+
+    uint64_t hint_tree = 1024, hint_twig = 0;   // what the previous chunk needed: the next one starts there instead of doubling its way up
+
+    // grow() and - if the terrain has water - Ocroot::build behind it, both on the device.  Node words and bricks stay in HBM:
+    // *tree_dev / *bricks_dev receive the device arrays (caller owns them, hipFree), c.trees_on_device / c.twigs_on_device
+    // their lengths; the host copies are fetched on request (device.hip: fetch_pools).
+    int grow(ChunkPools &c, const float position[3], float size, uint32_t depth, const DevPyramid &P, const TerrainParams &tp, hipStream_t s,
+             DeviceFiller &filler, uint32_t **tree_dev, uint16_t **bricks_dev)
+    {
+        c.position[0] = position[0]; c.position[1] = position[1]; c.position[2] = position[2];
+        c.size = size; c.depth = depth;
+        c.tree_capacity = 16; c.twig_capacity = 16;
+        uint64_t trees = 1, twigs = 0;
+        int rc;
+        if ((rc = frontier.reserve(1, false, s)) != SVO_OK || (rc = tree.reserve(hint_tree, false, s)) != SVO_OK ||
+            (hint_twig && (rc = twig.reserve(hint_twig, false, s)) != SVO_OK) || (rc = totals.reserve(64, false, s)) != SVO_OK) return rc;
+        if (!h_totals) BUILD_TRY(hipHostMalloc((void **)&h_totals, 2 * sizeof(uint32_t)));
+        BUILD_TRY(hipMemsetAsync(totals.p, 0, 64 * sizeof(uint32_t), s));
+        const Cell root = { position[0], position[1], position[2], 0u };
+        BUILD_TRY(hipMemcpyAsync(frontier.p, &root, sizeof root, hipMemcpyHostToDevice, s));
+        uint32_t n = 1;
+        float edge = size;
+        GrowArgs G{};
+        G.px = position[0]; G.py = position[1]; G.pz = position[2]; G.size = size; G.depth = depth;
+        const bool coarse = tp.coarse_depth >= TWIG_LEVELS && tp.coarse_depth < depth;
+        G.coarse_depth = coarse ? tp.coarse_depth : 0;
+        for (int a = 0; a < 3; ++a) { G.rmin[a] = tp.refine_min[a]; G.rmax[a] = tp.refine_max[a]; }
+
+        for (uint32_t level = 0; n > 0; ++level) {
+            const float half = edge / 2;
+            G.level = level; G.edge = edge;
+            if (level >= 32) { set_error("device builder: more than 32 levels"); return SVO_ERR_UNSUPPORTED; }
+            if ((rc = word.reserve(n, false, s)) != SVO_OK || (rc = flags.reserve(n, false, s)) != SVO_OK || (rc = rank.reserve(n, false, s)) != SVO_OK) return rc;
+            hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256)), dim3(256), 0, s, frontier.p, n, G, P, word.p, flags.p, totals.p + 2 * level);
+            size_t need = 0;
+            BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, flags.p, rank.p, (int)n, s));
+            if ((rc = scan_tmp.reserve(need + 16, false, s)) != SVO_OK) return rc;
+            BUILD_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, need, flags.p, rank.p, (int)n, s));
+            BUILD_TRY(hipMemcpyAsync(h_totals, totals.p + 2 * level, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            BUILD_TRY(hipStreamSynchronize(s));
+            const uint64_t nb = h_totals[0], nt = h_totals[1];
+            if (trees + 8 * nb >= (1ull << 30) || twigs + nt >= (1ull << 30)) { set_error("device builder: chunk exceeds the 30-bit node offset"); return SVO_ERR_UNSUPPORTED; }
+            if ((rc = tree.reserve(trees + 8 * nb, true, s)) != SVO_OK || (rc = twig.reserve((twigs + nt) * TWIG_WORDS, true, s)) != SVO_OK ||
+                (rc = next.reserve(std::max<uint64_t>(8 * nb, 1), false, s)) != SVO_OK || (rc = jobs.reserve(std::max<uint64_t>(nt, 1), false, s)) != SVO_OK) return rc;
+            hipLaunchKernelGGL(k_emit, dim3(blocks_for(n, 256)), dim3(256), 0, s, frontier.p, n, half, word.p, rank.p,
+                               (uint32_t)trees, (uint32_t)twigs, tree.p, next.p, jobs.p);
+            if (nt) hipLaunchKernelGGL(k_bricks_rows, dim3(blocks_for(nt * 4, 256)), dim3(256), 0, s, jobs.p, (uint32_t)nt, G, P, twig.p);
+            BUILD_TRY(hipGetLastError());
+            // capacity bookkeeping exactly as the host builder (src/Octree.cpp:149-150,160-161)
+            if (nb) while (trees + 8 * nb >= c.tree_capacity) c.tree_capacity *= 2;
+            while (twigs + nt > c.twig_capacity) c.twig_capacity *= 2;
+            trees += 8 * nb; twigs += nt;
+            std::swap(frontier.p, next.p); std::swap(frontier.cap, next.cap);
+            n = (uint32_t)(8 * nb);
+            edge = half;
+        }
+        if (tp.water) {     // World::g_chunk, src/World.cpp:316-320: everything of the chunk below the water level
+            const float hi[3] = { position[0] + size, tp.water_level, position[2] + size };
+            if ((rc = filler.fill(c, position, hi, tp.water_material, tree, trees, twig, twigs, s)) != SVO_OK) return rc;
+        }
+        c.tree.clear(); c.twig.clear();
+        c.trees_on_device = trees;
+        c.twigs_on_device = twigs;
+        hint_tree = std::max<uint64_t>(hint_tree, tree.cap); hint_twig = std::max<uint64_t>(hint_twig, twig.cap);
+        *tree_dev = tree.p; *bricks_dev = twig.p;   // hand the arrays over; the next chunk gets fresh ones
+        tree.p = nullptr; tree.cap = 0;
+        twig.p = nullptr; twig.cap = 0;
+        return SVO_OK;
+    }
+};
+
+static int positive_mod_b(int n, int m) { return (m + (n % m)) % m; }
+
+// World::init on the device, pools left in HBM: noise, mips, grow() and the water fill (Ocroot::build) as kernels (above).
+// Neither node words nor bricks visit the host (fetched on request: device.hip, fetch_pools).  The pools are packed exactly as
+// svo_world_upload packs them; the world is uploaded to `device` when this returns.
 static int generate_world_resident_impl(svo_world &w, int device)
 {
     const bool timing = std::getenv("SVO_BUILD_TIMING") != nullptr;
@@ -405,15 +624,18 @@ static int generate_world_resident_impl(svo_world &w, int device)
     BUILD_TRY(hipSetDevice(device));
     std::vector<ChunkPools> &chunks = w.chunks;
     chunks.assign((size_t)gw * gh * gd, ChunkPools());
-    std::vector<uint16_t *> bricks(chunks.size(), nullptr);             // per chunk: its bricks as grow() left them in HBM
-    std::vector<uint64_t> grown(chunks.size(), 0);
-    std::vector<std::vector<BrickOp>> ops(chunks.size());
-    struct Cleanup { std::vector<uint16_t *> &b; ~Cleanup() { for (uint16_t *p : b) if (p) (void)hipFree(p); } } cleanup{ bricks };
+    std::vector<uint16_t *> bricks(chunks.size(), nullptr);             // per chunk: its pools as the builder left them in HBM
+    std::vector<uint32_t *> trees(chunks.size(), nullptr);
+    struct Cleanup {
+        std::vector<uint16_t *> &b; std::vector<uint32_t *> &t;
+        ~Cleanup() { for (uint16_t *p : b) if (p) (void)hipFree(p); for (uint32_t *p : t) if (p) (void)hipFree(p); }
+    } cleanup{ bricks, trees };
     const uint32_t res = tp.pyramid_resolution ? tp.pyramid_resolution : (1u << tp.depth);
     hipStream_t s = nullptr;
     {
         DevicePyramidBuilder pyr;
         DeviceGrower grower;
+        DeviceFiller filler;
         for (int zi = 0; zi < gd; ++zi)
             for (int xi = 0; xi < gw; ++xi) {
                 const int cx = ccm[0] + xi, cz = ccm[2] + zi;
@@ -425,69 +647,32 @@ static int generate_world_resident_impl(svo_world &w, int device)
                     const int idx = positive_mod_b(cy, gh) * gw * gd + positive_mod_b(cz, gd) * gw + positive_mod_b(cx, gw);
                     ChunkPools &c = chunks[(size_t)idx];
                     const float pos[3] = { (float)cx * (float)chunksize, (float)cy * (float)chunksize, (float)cz * (float)chunksize };
-                    rc = grower.grow(c, pos, (float)chunksize, tp.depth, pyr.view, tp, s, &bricks[(size_t)idx]);
+                    rc = grower.grow(c, pos, (float)chunksize, tp.depth, pyr.view, tp, s, filler, &trees[(size_t)idx], &bricks[(size_t)idx]);
                     if (rc != SVO_OK) return rc;
-                    grown[(size_t)idx] = c.twigs_on_device;
                 }
             }
+        lapt("noise + mips + grow + fill");
     }
-    lapt("noise + mips + grow (device)");
-    if (tp.water) {     // Ocroot::build on the node words (host threads, all chunks in parallel); brick edits are recorded
-        int nthreads = tp.threads > 0 ? tp.threads : (int)std::thread::hardware_concurrency();
-        nthreads = std::max(1, std::min<int>(nthreads, (int)chunks.size()));
-        std::atomic<size_t> cursor{ 0 };
-        std::atomic<int> failed{ 0 };           // nothing may escape a std::thread (std::terminate): report after join
-        auto worker = [&]() {
-            try {
-                for (;;) {
-                    const size_t i = cursor.fetch_add(1);
-                    if (i >= chunks.size()) break;
-                    ChunkPools &c = chunks[i];
-                    const float hi[3] = { c.position[0] + c.size, tp.water_level, c.position[2] + c.size };
-                    fill_box_plan(c, c.position, hi, (uint16_t)tp.water_material, ops[i]);
-                }
-            } catch (...) {
-                failed.store(1);
-                cursor.store(chunks.size());
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto &t : pool) t.join();
-        if (failed.load()) { set_error("svo_world_generate: out of host memory in the water fill"); return SVO_ERR_OUT_OF_MEMORY; }
-    }
-    lapt("water fill plan (host)");
     // pack: the layout of svo_world_upload
     int rc = plan_pools(w);
     if (rc != SVO_OK) return rc;
     if ((rc = alloc_pools(w, device)) != SVO_OK) return rc;
     lapt("alloc pools");
-    DevBuf<DevBrickOp> d_ops;
     for (size_t i = 0; i < chunks.size(); ++i) {
-        ChunkPools &c = chunks[i];
+        const ChunkPools &c = chunks[i];
         const DevChunk &e = w.table[i];
-        BUILD_TRY(hipMemcpyAsync(w.d_tree + e.tree_off, c.tree.data(), c.tree.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        const uint64_t before = grown[i], now = c.twig_count();
-        uint16_t *slot = w.d_twig + e.twig_off * TWIG_WORDS;
-        if (before) BUILD_TRY(hipMemcpyAsync(slot, bricks[i], before * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        if (now > before) BUILD_TRY(hipMemsetAsync(slot + before * TWIG_WORDS, 0, (now - before) * TWIG_WORDS * sizeof(uint16_t), s));
-        if (!ops[i].empty()) {
-            if ((rc = d_ops.reserve(ops[i].size(), false, s)) != SVO_OK) return rc;
-            BUILD_TRY(hipMemcpyAsync(d_ops.p, ops[i].data(), ops[i].size() * sizeof(BrickOp), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_brick_fill, dim3(blocks_for((uint64_t)ops[i].size() * 64, 256)), dim3(256), 0, s, w.d_twig,
-                               d_ops.p, (uint32_t)ops[i].size(), (uint64_t)e.twig_off,
-                               c.position[0], c.position[1], c.position[2], c.position[0] + c.size, tp.water_level, c.position[2] + c.size,
-                               (uint32_t)tp.water_material);
-            BUILD_TRY(hipGetLastError());
-            BUILD_TRY(hipStreamSynchronize(s));             // d_ops and ops[i] are reused / freed
-        }
-        if ((rc = launch_brick_masks(w, e.twig_off, now, s)) != SVO_OK) return rc;
-        BUILD_TRY(hipStreamSynchronize(s));
-        (void)hipFree(bricks[i]); bricks[i] = nullptr;
+        BUILD_TRY(hipMemcpyAsync(w.d_tree + e.tree_off, trees[i], c.trees_on_device * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        if (c.twigs_on_device)
+            BUILD_TRY(hipMemcpyAsync(w.d_twig + e.twig_off * TWIG_WORDS, bricks[i], c.twigs_on_device * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        if ((rc = launch_brick_masks(w, e.twig_off, c.twigs_on_device, s)) != SVO_OK) return rc;
     }
-    lapt("pack + brick fill + masks");
-    BUILD_TRY(hipMemcpy(w.d_chunks, w.table.data(), chunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice));
+    BUILD_TRY(hipMemcpyAsync(w.d_chunks, w.table.data(), chunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice, s));
+    BUILD_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        (void)hipFree(bricks[i]); bricks[i] = nullptr;
+        (void)hipFree(trees[i]); trees[i] = nullptr;
+    }
+    lapt("pack + masks");
     if ((rc = build_wide_all(w, s)) != SVO_OK) return rc;
     lapt("wide trees");
     BUILD_TRY(hipDeviceSynchronize());

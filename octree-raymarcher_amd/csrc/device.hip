@@ -170,7 +170,7 @@ int plan_pools(svo_world &w)
     uint64_t tcur = 0, bcur = 0;
     for (size_t i = 0; i < n; ++i) {
         const ChunkPools &c = w.chunks[i];
-        const uint64_t tcap = std::max<uint64_t>(c.tree_capacity, c.tree.size());
+        const uint64_t tcap = std::max<uint64_t>(c.tree_capacity, c.tree_count());
         const uint64_t bcap = std::max<uint64_t>(c.twig_capacity, c.twig_count());
         const uint64_t base = ((tcur + 8) & ~(uint64_t)7) - 1;          // base % 8 == 7, base >= tcur
         DevChunk &e = w.table[i];
@@ -209,17 +209,25 @@ int alloc_pools(svo_world &w, int device)
     return SVO_OK;
 }
 
-// A chunk built on the device keeps its bricks there until somebody asks for the host copy.
-int fetch_bricks(svo_world &w, int chunk)
+// A chunk built on the device keeps its node words and bricks there until somebody asks for the host copy.
+int fetch_pools(svo_world &w, int chunk)
 {
     ChunkPools &c = w.chunks[(size_t)chunk];
-    if (!c.twigs_on_device) return SVO_OK;
-    if (w.device < 0 || !w.d_twig) { set_error("fetch_bricks: the device copy is gone"); return SVO_ERR_NOT_UPLOADED; }
+    if (!c.twigs_on_device && !c.trees_on_device) return SVO_OK;
+    if (w.device < 0 || !w.d_twig || !w.d_tree) { set_error("fetch_pools: the device copy is gone"); return SVO_ERR_NOT_UPLOADED; }
     HIP_TRY(hipSetDevice(w.device));
-    const uint64_t n = c.twigs_on_device;
-    c.twig.resize(n * TWIG_WORDS);
-    HIP_TRY(hipMemcpy(c.twig.data(), w.d_twig + w.table[(size_t)chunk].twig_off * TWIG_WORDS, n * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost));
-    c.twigs_on_device = 0;
+    if (c.trees_on_device) {
+        const uint64_t n = c.trees_on_device;
+        c.tree.resize(n);
+        HIP_TRY(hipMemcpy(c.tree.data(), w.d_tree + w.table[(size_t)chunk].tree_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        c.trees_on_device = 0;
+    }
+    if (c.twigs_on_device) {
+        const uint64_t n = c.twigs_on_device;
+        c.twig.resize(n * TWIG_WORDS);
+        HIP_TRY(hipMemcpy(c.twig.data(), w.d_twig + w.table[(size_t)chunk].twig_off * TWIG_WORDS, n * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        c.twigs_on_device = 0;
+    }
     return SVO_OK;
 }
 
@@ -232,7 +240,7 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
     const uint32_t levels = c.depth - TWIG_LEVELS;
     const uint32_t nw = levels == 0 ? 1u : (levels + 1u) / 2u;
     const int pad = (int)(2u * nw - levels);
-    const uint64_t B = c.tree.size() / 8 + 1;                           // most BRANCH nodes (= wide nodes) a level can have
+    const uint64_t B = c.tree_count() / 8 + 1;                          // most BRANCH nodes (= wide nodes) a level can have
     uint32_t *front = w.d_wscratch, *next = front + B, *flag = next + B, *rank = flag + 64 * B;
     const uint32_t *tree = w.d_tree + e.tree_off;
     HIP_TRY(hipMemsetAsync(front, 0, sizeof(uint32_t), s));             // the top wide node expands reference node 0
@@ -290,7 +298,7 @@ static bool wide_fits(const svo_world &w, int chunk)
     const ChunkPools &c = w.chunks[(size_t)chunk];
     // (a wide entry keeps its reference node's level in 5 bits; WIDE_MAX_LEVELS branch levels, i.e. chunk depth <= 24, are marched)
     // and the builder scans one level's entries (64 per wide node) with 32-bit counts: < 2^31 entries per chunk
-    return c.depth - TWIG_LEVELS <= WIDE_MAX_LEVELS && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && (c.tree.size() / 8 + 1) * 64 < (1ull << 31);
+    return c.depth - TWIG_LEVELS <= WIDE_MAX_LEVELS && c.twig_count() <= (uint64_t)WIDE_PAYLOAD_MASK && (c.tree_count() / 8 + 1) * 64 < (1ull << 31);
 }
 
 // Wide trees of every chunk: a count pass into scratch sizes the pool (each chunk's slot = its wide nodes + 25 % + 16),
@@ -323,7 +331,7 @@ int build_wide_all(svo_world &w, void *stream)
     drop_wide(w);
     bool fits = true;
     uint64_t largest = 0;
-    for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree.size()); if (!wide_fits(w, (int)i)) fits = false; }
+    for (size_t i = 0; i < n; ++i) { largest = std::max<uint64_t>(largest, w.chunks[i].tree_count()); if (!wide_fits(w, (int)i)) fits = false; }
     w.wtable.assign(n, DevWide()); w.wide_slot.assign(n, 0);
     if (!fits) return SVO_OK;                                           // the literal kernel marches such a world
     int rc = reserve_wide_scratch(w, largest);
@@ -377,10 +385,10 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
     const ChunkPools &c = w.chunks[(size_t)chunk];
     // any failure below leaves the chunk's old wide tree in the pool while tree[] has changed: the pool is dropped
     // (wide_ok = false) and the literal kernel takes over until a full rebuild succeeds
-    int rc = reserve_wide_scratch(w, c.tree.size());
+    int rc = reserve_wide_scratch(w, c.tree_count());
     if (rc == SVO_OK && wide_fault_injected()) { set_error("wide tree: injected allocation failure"); rc = SVO_ERR_OUT_OF_MEMORY; }
     if (rc != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
-    const uint64_t Bmax = c.tree.size() / 8 + 1;
+    const uint64_t Bmax = c.tree_count() / 8 + 1;
     uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
     uint64_t count = 0;
     if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
@@ -417,10 +425,10 @@ static int world_upload_impl(svo_world *w, int device, bool force = false)
     if (device < 0 || device >= ndev) { set_error("svo_world_upload: device index out of range"); return SVO_ERR_INVALID_ARG; }
     // a world generated on this device is already resident there, pools packed exactly as below
     bool resident_only = false;
-    for (const ChunkPools &c : w->chunks) resident_only |= c.twigs_on_device != 0;
+    for (const ChunkPools &c : w->chunks) resident_only |= c.twigs_on_device != 0 || c.trees_on_device != 0;
     if (resident_only && w->device == device && !force) return SVO_OK;
     for (size_t i = 0; i < w->chunks.size(); ++i) {                     // moving elsewhere: the host copy must be complete first
-        const int rc = fetch_bricks(*w, (int)i);
+        const int rc = fetch_pools(*w, (int)i);
         if (rc != SVO_OK) return rc;
     }
     int rc = plan_pools(*w);
@@ -472,7 +480,8 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
     if (next.size != (float)w->chunksize) { set_error("svo_world_update: chunk size must equal chunksize"); return SVO_ERR_UNSUPPORTED; }
     w->chunks[(size_t)chunk].tree.swap(next.tree);
     w->chunks[(size_t)chunk].twig.swap(next.twig);
-    w->chunks[(size_t)chunk].twigs_on_device = 0;       // the caller's bricks replace whatever lived only on the device
+    w->chunks[(size_t)chunk].twigs_on_device = 0;       // the caller's pools replace whatever lived only on the device
+    w->chunks[(size_t)chunk].trees_on_device = 0;
     ChunkPools &c = w->chunks[(size_t)chunk];
     std::memcpy(c.position, next.position, sizeof c.position);
     c.size = next.size; c.depth = next.depth;

@@ -234,7 +234,6 @@ struct Filler {
     Box region;
     uint16_t material;
     DirtyRange &dt, &dw;
-    std::vector<BrickOp> *plan = nullptr;       // non-null: bricks live on the device, record what to do with them
 
     void touch_node(uint64_t i) { dt.left = std::min(dt.left, i); dt.right = std::max(dt.right, i + 1); }
     void touch_brick(uint64_t i) { dw.left = std::min(dw.left, i); dw.right = std::max(dw.right, i + 1); }
@@ -254,8 +253,7 @@ struct Filler {
             } else if (level == c.depth - TWIG_LEVELS) {
                 if (c.twig_count() >= c.twig_capacity) { c.twig_capacity *= 2; dw.realloc = true; }
                 const uint64_t brick = c.twig_count();
-                if (plan) c.twigs_on_device++;
-                else c.twig.resize(c.twig.size() + TWIG_WORDS, 0);
+                c.twig.resize(c.twig.size() + TWIG_WORDS, 0);
                 touch_brick(brick);
                 touch_node(slot);
                 c.tree[slot] = node_make(TWIG, (uint32_t)brick);
@@ -274,7 +272,6 @@ struct Filler {
             const float voxel = edge / (float)(1 << TWIG_LEVELS);
             const uint64_t brick = node_offset(word);
             touch_brick(brick);
-            if (plan) { plan->push_back({ brick, x, y, z, voxel }); return; }
             uint16_t *cells = c.twig.data() + brick * TWIG_WORDS;
             for (uint32_t cz = 0; cz < TWIG_SIZE; ++cz)
                 for (uint32_t cy = 0; cy < TWIG_SIZE; ++cy)
@@ -303,13 +300,6 @@ void fill_box(ChunkPools &c, const float lo[3], const float hi[3], uint16_t mate
 {
     dtree = DirtyRange(); dtwig = DirtyRange();
     Filler f{ c, { { lo[0], lo[1], lo[2] }, { hi[0], hi[1], hi[2] } }, material, dtree, dtwig };
-    f.visit(0, c.position[0], c.position[1], c.position[2], c.size, 0);
-}
-
-void fill_box_plan(ChunkPools &c, const float lo[3], const float hi[3], uint16_t material, std::vector<BrickOp> &ops)
-{
-    DirtyRange dtree, dtwig;
-    Filler f{ c, { { lo[0], lo[1], lo[2] }, { hi[0], hi[1], hi[2] } }, material, dtree, dtwig, &ops };
     f.visit(0, c.position[0], c.position[1], c.position[2], c.size, 0);
 }
 

@@ -22,9 +22,12 @@ struct ChunkPools {
     std::vector<uint32_t> tree;                        // node words
     std::vector<uint16_t> twig;                        // 64 cells per brick
     // > 0: the chunk was built on the device and its bricks have not been fetched to the host yet (`twig` is empty);
-    // svo_world_chunk / a move to another device fetch them (device.hip: fetch_bricks)
+    // svo_world_chunk / a move to another device fetch them (device.hip: fetch_pools)
     uint64_t twigs_on_device = 0;
     uint64_t twig_count() const { return twigs_on_device ? twigs_on_device : twig.size() / TWIG_WORDS; }
+    // the same for the node words (`tree` is empty until fetched): the device builder runs Ocroot::build on the device too
+    uint64_t trees_on_device = 0;
+    uint64_t tree_count() const { return trees_on_device ? trees_on_device : tree.size(); }
     void reserve_tree(uint64_t need);
 };
 
@@ -55,11 +58,6 @@ float simplex2(float x, float y);
 void  grow_chunk(ChunkPools &c, const float position[3], float size, uint32_t depth, const HeightPyramid &pyr,
                  const TerrainParams *sparse = nullptr);
 void  fill_box(ChunkPools &c, const float lo[3], const float hi[3], uint16_t material, DirtyRange &dtree, DirtyRange &dtwig);
-// The same edit of a chunk whose bricks live on the device (c.twigs_on_device): the node words are edited on the host,
-// every brick the fill touches - existing ones and the new ones it appends (index >= the old count, to be zeroed
-// first) - is recorded as one BrickOp for the device to apply (builder.hip: k_brick_fill).
-struct BrickOp { uint64_t brick; float x, y, z, voxel; };
-void  fill_box_plan(ChunkPools &c, const float lo[3], const float hi[3], uint16_t material, std::vector<BrickOp> &ops);
 int   generate_world(int w, int h, int d, int chunksize, const int chunkcoordmin[3], const TerrainParams &tp,
                      std::vector<ChunkPools> &chunks);
 

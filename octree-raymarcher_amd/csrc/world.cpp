@@ -236,7 +236,7 @@ int svo_world_info_get(const svo_world *w, svo_world_info *o)
     o->width = w->width; o->height = w->height; o->depth = w->depth; o->chunksize = w->chunksize;
     for (int i = 0; i < 3; ++i) o->chunkcoordmin[i] = w->chunkcoordmin[i];
     o->uploaded_device = w->device;
-    for (const ChunkPools &c : w->chunks) { o->total_trees += c.tree.size(); o->total_twigs += c.twig_count(); }
+    for (const ChunkPools &c : w->chunks) { o->total_trees += c.tree_count(); o->total_twigs += c.twig_count(); }
     o->tree_pool_bytes = w->tree_pool_cap * sizeof(uint32_t);
     o->twig_pool_bytes = w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t);
     o->mask_pool_bytes = w->twig_pool_cap * sizeof(uint64_t);
@@ -250,8 +250,8 @@ int svo_world_info_get(const svo_world *w, svo_world_info *o)
 int svo_world_chunk(const svo_world *w, int i, svo_chunk_desc *o)
 {
     if (!w || !o || i < 0 || i >= (int)w->chunks.size()) return SVO_ERR_INVALID_ARG;
-    if (w->chunks[(size_t)i].twigs_on_device) {         // built on the device: the host copy of the bricks is made on first request
-        const int rc = fetch_bricks(*const_cast<svo_world *>(w), i);
+    if (w->chunks[(size_t)i].twigs_on_device || w->chunks[(size_t)i].trees_on_device) {   // built on the device: the host copy is made on first request
+        const int rc = fetch_pools(*const_cast<svo_world *>(w), i);
         if (rc != SVO_OK) return rc;
     }
     const ChunkPools &c = w->chunks[(size_t)i];

@@ -55,7 +55,7 @@ int  release_device(svo_world &w);
 int  plan_pools(svo_world &w);                    // slots, offsets and pool sizes from the chunks' capacities (host only)
 int  alloc_pools(svo_world &w, int device);       // hipMalloc + clear of the pools planned above; sets w.device
 int  launch_brick_masks(svo_world &w, uint64_t first, uint64_t count, void *stream);
-int  fetch_bricks(svo_world &w, int chunk);       // bricks that live only on the device -> host copy of that chunk
+int  fetch_pools(svo_world &w, int chunk);        // node words / bricks that live only on the device -> host copy of that chunk
 int  build_wide_all(svo_world &w, void *stream);  // wide trees (wide_tree.hip.h) of all chunks from the node words in the tree pool
 // builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
 int  generate_world_resident(svo_world &w, int device);

@@ -1,8 +1,8 @@
-"""Device-side world generation (csrc/builder.hip): noise, min/max mips and grow() as kernels, the water
-fill's brick edits applied in HBM, pools left on the device (the world is uploaded when svo_world_generate returns).
+"""Device-side world generation (csrc/builder.hip): noise, min/max mips, grow() and the water fill
+(Ocroot::build) as kernels, pools left on the device (the world is uploaded when svo_world_generate returns).
 The pools must be bit-identical to the oracle's restatement of grow / BoundsPyramid / Ocroot::build
-(OracleWorld.generate) and to the host builder's; the march over a device-built world - whose bricks never visited the
-host - must equal the oracle's march over the oracle's world."""
+(OracleWorld.generate) and to the host builder's; the march over a device-built world - whose node words and bricks
+never visited the host - must equal the oracle's march over the oracle's world."""
 import time
 
 import numpy as np
@@ -19,6 +19,16 @@ CASES = [
     dict(w=1, h=1, d=1, depth=9, water=False),
     dict(w=1, h=1, d=1, depth=10, amplitude=30.0, yshift=50.0, water_level=40.0),
     dict(w=1, h=1, d=1, depth=12, water=False, coarse_depth=8, refine_box=((60, -1e9, -1e9), (68, 1e9, 1e9))),
+    # the water fill (Ocroot::build) on the device: planes on and off the node lattice, above and below all terrain,
+    # in a chunk whose bricks sit at two levels (the fill splits the coarse EMPTY nodes it cuts down to depth-2)
+    dict(w=1, h=1, d=1, depth=8, water_level=8.0),
+    dict(w=1, h=1, d=1, depth=8, water_level=16.0, amplitude=20.0),
+    dict(w=1, h=1, d=1, depth=7, water_level=33.37),
+    dict(w=1, h=2, d=1, depth=6, water_level=128.0),
+    dict(w=1, h=2, d=1, depth=6, water_level=300.0),
+    dict(w=1, h=1, d=1, depth=6, water_level=-100.0),
+    dict(w=2, h=1, d=1, depth=9, water_level=11.3, coarse_depth=6, refine_box=((100, -1e9, -1e9), (140, 1e9, 1e9))),
+    dict(w=1, h=1, d=1, depth=11, water_level=6.0, chunkcoordmin=(5, 0, -3)),
 ]
 
 
@@ -33,6 +43,9 @@ def test_device_built_world_equals_host_built(svo, case):
         assert a["position"] == b["position"] and a["depth"] == b["depth"]
         assert np.array_equal(a["tree"], b["tree"]), f"chunk {i}: node words differ"
         assert np.array_equal(a["twig"], b["twig"]), f"chunk {i}: bricks differ"
+    # Ocroot's storage sizes (treestoragesize / twigstoragesize doubling) size the pool slots: the same either way
+    H.upload(0)
+    assert H.info.tree_pool_bytes == D.info.tree_pool_bytes and H.info.twig_pool_bytes == D.info.twig_pool_bytes
     H.destroy(); D.destroy()
 
 
