@@ -262,7 +262,9 @@ int svo_world_update(svo_world *, int chunk, const svo_chunk_desc *desc,
 
 /* World::shift (src/World.cpp:334-378): slide the grid by one chunk along one axis (offset = +-1 on exactly one
  * axis).  The entering plane of chunks is generated with the world's terrain parameters and replaces, at its
- * toroidal World::index(), the plane that leaves; chunkcoordmin moves.  Only for worlds made by svo_world_generate. */
+ * toroidal World::index(), the plane that leaves; chunkcoordmin moves.  Only for worlds made by svo_world_generate.
+ * On an uploaded world the plane is generated on the device the pools live on and installed device-to-device (host
+ * copies of those chunks are made on request, svo_world_chunk); otherwise on the host. */
 int svo_world_shift(svo_world *, const int offset[3]);
 
 /* ---- the hot path ------------------------------------------------------------------------ */

@@ -679,6 +679,49 @@ static int generate_world_resident_impl(svo_world &w, int device)
     return SVO_OK;
 }
 
+// World::shift (src/World.cpp:334-378) on an uploaded world: the plane of chunks entering the grid is generated on the device
+// the pools live on (g_pyramid + g_chunk as in generate_world_resident_impl) and takes the slots of the plane that leaves -
+// the toroidal index of a chunk coordinate does not depend on chunkcoordmin -, then chunkcoordmin moves.
+static int shift_world_resident_impl(svo_world &w, int axis, int sign)
+{
+    const TerrainParams &tp = w.terrain;
+    const int dims[3] = { w.width, w.height, w.depth };
+    const int u = sign < 0 ? w.chunkcoordmin[axis] - 1 : w.chunkcoordmin[axis] + dims[axis];
+    const uint32_t res = tp.pyramid_resolution ? tp.pyramid_resolution : (1u << tp.depth);
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = w.chunkcoordmin[a]; hi[a] = w.chunkcoordmin[a] + dims[a]; }
+    lo[axis] = u; hi[axis] = u + 1;
+    BUILD_TRY(hipSetDevice(w.device));
+    hipStream_t s = nullptr;
+    DevicePyramidBuilder pyr;
+    DeviceGrower grower;
+    DeviceFiller filler;
+    for (int cz = lo[2]; cz < hi[2]; ++cz)
+        for (int cx = lo[0]; cx < hi[0]; ++cx) {
+            int rc = pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift,
+                               (float)cz * (float)res + (float)tp.seed, s);
+            if (rc != SVO_OK) return rc;
+            for (int cy = lo[1]; cy < hi[1]; ++cy) {
+                ChunkPools c;
+                const float pos[3] = { (float)cx * (float)w.chunksize, (float)cy * (float)w.chunksize, (float)cz * (float)w.chunksize };
+                uint32_t *tree_dev = nullptr;
+                uint16_t *twig_dev = nullptr;
+                rc = grower.grow(c, pos, (float)w.chunksize, tp.depth, pyr.view, tp, s, filler, &tree_dev, &twig_dev);
+                if (rc == SVO_OK) rc = install_resident_chunk(w, svo_world_index(&w, cx, cy, cz), c, tree_dev, twig_dev);
+                (void)hipFree(tree_dev); (void)hipFree(twig_dev);
+                if (rc != SVO_OK) return rc;
+            }
+        }
+    w.chunkcoordmin[axis] += sign;
+    return SVO_OK;
+}
+
+int shift_world_resident(svo_world &w, int axis, int sign)
+{
+    try { return shift_world_resident_impl(w, axis, sign); }
+    catch (const std::bad_alloc &) { set_error("svo_world_shift: out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+}
+
 int generate_world_resident(svo_world &w, int device)
 {
     try {

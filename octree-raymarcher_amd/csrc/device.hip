@@ -547,6 +547,66 @@ int svo_world_update(svo_world *w, int chunk, const svo_chunk_desc *desc,
     catch (...) { set_error("svo_world_update: unexpected exception"); return SVO_ERR_HIP; }
 }
 
+} // extern "C"
+
+namespace svo {
+
+// svo_world_update's device half for a chunk whose new pools already lie in HBM (World::shift on an uploaded world,
+// builder.hip): same ordering rule (the device is drained first), same slot logic - in place if it fits, at the pools' tails
+// if they have room; otherwise the chunk comes to the host and the whole world is packed again.
+int install_resident_chunk(svo_world &w, int chunk, const ChunkPools &meta, const uint32_t *tree_dev, const uint16_t *twig_dev)
+{
+    if (w.device < 0 || chunk < 0 || chunk >= (int)w.chunks.size()) return SVO_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(w.device));
+    HIP_TRY(hipDeviceSynchronize());
+    ChunkPools &c = w.chunks[(size_t)chunk];
+    const uint64_t trees = meta.trees_on_device, twigs = meta.twigs_on_device;
+    std::memcpy(c.position, meta.position, sizeof c.position);
+    c.size = meta.size; c.depth = meta.depth;
+    c.tree_capacity = std::max(c.tree_capacity, meta.tree_capacity);    // (svo_world_update keeps the slot's capacity as the floor too)
+    c.twig_capacity = std::max(c.twig_capacity, meta.twig_capacity);
+    std::vector<uint32_t>().swap(c.tree);
+    std::vector<uint16_t>().swap(c.twig);
+    c.trees_on_device = trees; c.twigs_on_device = twigs;
+    classify_world(w);
+    DevChunk &e = w.table[(size_t)chunk];
+    const bool tree_fits = trees <= w.tree_slot[(size_t)chunk], twig_fits = twigs <= w.twig_slot[(size_t)chunk];
+    const bool trace = std::getenv("SVO_BUILD_TIMING") != nullptr;
+    if (trace) std::fprintf(stderr, "[svo install] chunk %d: %s\n", chunk, tree_fits && twig_fits ? "in place" : "outgrew its slot");
+    if (!tree_fits || !twig_fits) {
+        const uint64_t tbase = ((w.tree_pool_len + 8) & ~(uint64_t)7) - 1;
+        const uint64_t need_t = tree_fits ? 0 : c.tree_capacity, need_b = twig_fits ? 0 : c.twig_capacity;
+        if ((!tree_fits && tbase + need_t > w.tree_pool_cap) || (!twig_fits && w.twig_pool_len + need_b > w.twig_pool_cap)) {
+            // no room: this chunk's pools come to the host, then everything is fetched and packed afresh
+            if (trace) std::fprintf(stderr, "[svo install] chunk %d: no room at the tails, packing the world again\n", chunk);
+            c.tree.resize(trees); c.twig.resize(twigs * TWIG_WORDS);
+            c.trees_on_device = c.twigs_on_device = 0;
+            HIP_TRY(hipMemcpy(c.tree.data(), tree_dev, trees * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (twigs) HIP_TRY(hipMemcpy(c.twig.data(), twig_dev, twigs * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToHost));
+            return world_upload_impl(&w, w.device, true);
+        }
+        if (!tree_fits) { e.tree_off = tbase; w.tree_slot[(size_t)chunk] = need_t; w.tree_pool_len = tbase + need_t; }
+        if (!twig_fits) { e.twig_off = w.twig_pool_len; w.twig_slot[(size_t)chunk] = need_b; w.twig_pool_len += need_b; }
+    }
+    e.levels = c.depth - TWIG_LEVELS;
+    e.bmin[0] = c.position[0]; e.bmin[1] = c.position[1]; e.bmin[2] = c.position[2];
+    HIP_TRY(hipMemcpy(w.d_tree + e.tree_off, tree_dev, trees * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    if (twigs) {
+        HIP_TRY(hipMemcpy(w.d_twig + e.twig_off * TWIG_WORDS, twig_dev, twigs * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+        const int rc = launch_masks(w, e.twig_off, twigs, nullptr);
+        if (rc != SVO_OK) return rc;
+    }
+    HIP_TRY(hipMemcpy(w.d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
+    const int rc = rebuild_wide_chunk(w, chunk, nullptr);
+    if (rc != SVO_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return SVO_OK;
+}
+
+} // namespace svo
+
+extern "C" {
+
 // ---------------------------------------------------------------------------------------------
 static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
 {

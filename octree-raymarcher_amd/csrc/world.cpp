@@ -189,6 +189,8 @@ int svo_world_shift(svo_world *w, const int offset[3])
         if (offset[a] != 0) { if (axis >= 0 || (offset[a] != 1 && offset[a] != -1)) { set_error("svo_world_shift: offset must be a unit axis step"); return SVO_ERR_INVALID_ARG; } axis = a; }
     if (axis < 0) { set_error("svo_world_shift: offset must be a unit axis step"); return SVO_ERR_INVALID_ARG; }
     const int sign = offset[axis];
+    // an uploaded world: the entering plane is generated where the pools live (builder.hip), nothing visits the host
+    if (w->device >= 0) return shift_world_resident(*w, axis, sign);
     const int dims[3] = { w->width, w->height, w->depth };
     const int u = sign < 0 ? w->chunkcoordmin[axis] - 1 : w->chunkcoordmin[axis] + dims[axis];
     const TerrainParams &tp = w->terrain;

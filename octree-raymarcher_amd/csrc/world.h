@@ -57,6 +57,12 @@ int  alloc_pools(svo_world &w, int device);       // hipMalloc + clear of the po
 int  launch_brick_masks(svo_world &w, uint64_t first, uint64_t count, void *stream);
 int  fetch_pools(svo_world &w, int chunk);        // node words / bricks that live only on the device -> host copy of that chunk
 int  build_wide_all(svo_world &w, void *stream);  // wide trees (wide_tree.hip.h) of all chunks from the node words in the tree pool
+// a chunk built on the device (its pools at tree_dev / twig_dev, meta.trees_on_device nodes / meta.twigs_on_device bricks) takes
+// slot `chunk` of an uploaded world: device-to-device, no host copy made
+int  install_resident_chunk(svo_world &w, int chunk, const ChunkPools &meta, const uint32_t *tree_dev, const uint16_t *twig_dev);
+int  rebuild_wide_chunk(svo_world &w, int chunk, void *stream);
 // builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
 int  generate_world_resident(svo_world &w, int device);
+// builder.hip: World::shift's entering plane generated on the device the world is uploaded to
+int  shift_world_resident(svo_world &w, int axis, int sign);
 } // namespace svo

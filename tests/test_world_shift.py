@@ -73,3 +73,44 @@ def test_shift_of_a_device_resident_world(svo, oracle):
         assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"shifted resident/{k}")
     F = svo.World.generate(3, 1, 3, 128, 6, chunkcoordmin=ccm)
     worlds_equal(W, F, 9)
+
+
+@pytest.mark.gpu
+def test_many_shifts_of_a_resident_world_outgrow_slots(svo):
+    """A long walk: entering chunks differ in size from the ones they replace, so slots are outgrown, chunks move to the pools'
+    tails and, when those are full, the world is packed afresh (the device-only pools are fetched for that).  After every
+    leg the world equals a fresh one at the new chunkcoordmin."""
+    W = svo.World.generate(3, 1, 2, 128, 7, build_device=0, seed=3)
+    ccm = np.zeros(3, int)
+    cam_prm = dict(shadow=True)
+    for leg, off in enumerate([(1, 0, 0)] * 7 + [(0, 0, 1)] * 6 + [(-1, 0, 0)] * 3 + [(0, 1, 0)]):
+        W.shift(off)
+        ccm += np.array(off)
+        if leg % 4 == 3 or leg == 16:
+            F = svo.World.generate(3, 1, 2, 128, 7, chunkcoordmin=tuple(int(v) for v in ccm), build_device=0, seed=3)
+            lo = ccm.astype(float) * 128
+            o, d = random_rays(np.random.default_rng(leg), 8000, lo, lo + np.array([3, 1, 2]) * 128)
+            for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+                assert_gbuffer_equal(W.chunkmarch(o, d, kernel=k, **cam_prm), F.chunkmarch(o, d, kernel=k, **cam_prm), f"leg {leg}/kernel {k}")
+            if leg == 16:
+                worlds_equal(W, F, 6)
+            F.destroy()
+    W.destroy()
+
+
+@pytest.mark.gpu
+def test_shift_of_the_benchmark_world_is_fast(svo):
+    """C3's world (4x1x4 chunks, depth 12) slides one chunk: four chunks of 6 M nodes + 2 M bricks each are generated where the
+    pools live.  (The host path took seconds; the bound here is loose, the measured time is printed.)"""
+    import time
+    W = svo.World.generate(4, 1, 4, 128, 12, build_device=0)
+    t0 = time.time(); W.shift((1, 0, 0)); t1 = time.time(); W.shift((0, 0, -1)); t2 = time.time()
+    print(f"\nC3 world shift: {t1 - t0:.3f} s, {t2 - t1:.3f} s")
+    F = svo.World.generate(4, 1, 4, 128, 12, chunkcoordmin=(1, 0, -1), build_device=0)
+    assert W.info.total_trees == F.info.total_trees and W.info.total_twigs == F.info.total_twigs
+    for i in (0, 5, 15):
+        a, b = W.chunk(i, copy=False), F.chunk(i, copy=False)
+        assert a["position"] == b["position"]
+        assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
+    assert t2 - t0 < 2.0
+    W.destroy(); F.destroy()
