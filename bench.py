@@ -653,8 +653,8 @@ def run(args):
                     "issue_utilisation_this_run_at_2.4GHz": round(iss["instructions_per_frame"] * iss["cycles_per_instruction_weighted"] / simd_cycles, 4),
                     "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
-                    "note": "the march is bound by its chain of dependent loads per wave-step, not by issue: 22 % fewer instructions changed nothing at 5 waves per SIMD, "
-                            "a sixth wave per SIMD gave 9 % (DESIGN.md §5)"}
+                    "note": "a serialized launch is bound by each wave-step's chain (LDS read, one dependent load, ~215 instructions at six waves per SIMD) plus its drain: "
+                            "0.79 of the issue slots; with launches in flight the drains overlap and the run sits at the issue limit (DESIGN.md §5)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
