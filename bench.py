@@ -60,13 +60,16 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_STREAM_GBS = 6300.0        # ... and what a streaming copy achieves (6.29 TB/s measured)
 BAND = 8                       # rows per band == tile height of the stack kernel
-# N = 1: 8 frames per launch, 4 launches in flight.  A launch ends with a tail (its longest rays, each wave alone on its
-# SIMD); 8 frames behind one set of cursors pay it once, and the next launches' bulk runs under it.  Measured on the
-# camera path (final kernel): F x S = 4 x 4 -> 4 239 Mrays/s (launch 4.69 ms), 8 x 2 -> 4 243 (7.93 ms), 8 x 4 -> 4 278;
-# the small frames of C2 need the four launches in flight (6 218 -> 10 167).  The N > 1 rows come from one-GPU emulation
-# of a rank's share (--emulate-share) and are unmeasured on real multi-GPU hardware.
+# A launch ends with a tail (its longest rays, each wave alone on its SIMD); the frames of one launch, behind one set of cursors,
+# pay it once, and the next launch's bulk runs under it.  The N > 1 rows come from one-GPU emulation of a rank's share
+# (--emulate-share) and are unmeasured on real multi-GPU hardware.
 STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways
 FRAMES_PER_LAUNCH = {1: 8, 2: 8, 4: 16, 8: 16}      # consecutive frames marched by one launch (and shipped by one gather)
+# N = 1, per workload (launches in flight, frames per launch).  The depth-12 4x1x4 worlds: two launches of up to 16 frames give the
+# throughput of four of eight (6.9 Grays/s either way, 5.9 at 20 steps) and spread a launch's one drain over twice the frames
+# (serialized launch: 0.566 against 0.640 ms per frame).  C2's and C5's frames are short (0.2 - 0.3 ms): they want four launches in
+# flight (C2 with two: 6.5 against 11.1 Grays/s) and lose 2 - 7 % with 16 frames per launch.
+LAUNCH_SHAPE = {"c3_1080p_depth12_4x1x4_shadow": (2, 16), "c4_2160p_depth12_4x1x4_shadow": (2, 16)}
 PATH_CAMERAS = 32
 
 
@@ -285,7 +288,9 @@ def run(args):
     # launches in flight: a launch's critical path is its longest ray, so its tail leaves SIMDs idle that the next
     # launches' bulk fills; with N ranks a rank's share of a frame shrinks N-fold, so more frames ride in one launch
     # (both tables measured with --emulate-share on ONE GPU; unmeasured on real multi-GPU hardware)
-    S = args.streams if args.streams > 0 else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16)
+    one_gpu_whole_frame = max(world_size, args.emulate_share, 1) == 1
+    shape = LAUNCH_SHAPE.get(args.workload) if one_gpu_whole_frame else None
+    S = args.streams if args.streams > 0 else (shape[0] if shape else STREAMS_FOR_SHARE.get(max(world_size, args.emulate_share, 1), 16))
     # F consecutive frames form one group: ONE launch marches them (svo_trace_frames: the persistent waves drain once
     # per launch, not once per frame) and, at N > 1, ONE gather ships them.  Group j runs on stream j % S.
     if args.frames_per_launch > 0:
@@ -293,7 +298,7 @@ def run(args):
     elif multi and args.frames_per_gather > 0:
         G = args.frames_per_gather
     else:
-        G = FRAMES_PER_LAUNCH.get(max(world_size, args.emulate_share, 1), 4)
+        G = shape[1] if shape else FRAMES_PER_LAUNCH.get(max(world_size, args.emulate_share, 1), 4)
     G = max(1, min(G, svo.MAX_FRAMES))
     if args.frames_per_launch <= 0 and args.frames_per_gather <= 0:
         G = max(1, min(G, args.steps // S))     # a short run: fewer frames per launch rather than idle streams
@@ -642,7 +647,7 @@ def run(args):
             }
             if prof.get("issue"):
                 # instruction issue: ONE figure with its spread, measured by scripts/prof_round3.sh + scripts/microbench/valu_issue
-                # on the serialized 8-frame launch and replayed here; "this_run" prices the profiled instruction count per frame
+                # on the serialized launch of the reported shape and replayed here; "this_run" prices the profiled instruction count per frame
                 # against this run's time per frame at the nominal 2.4 GHz shader clock
                 iss = prof["issue"]
                 simd_cycles = 1024 * 2.4e9 * (elapsed / args.steps)
@@ -653,8 +658,8 @@ def run(args):
                     "issue_utilisation_this_run_at_2.4GHz": round(iss["instructions_per_frame"] * iss["cycles_per_instruction_weighted"] / simd_cycles, 4),
                     "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
-                    "note": "a serialized launch is bound by each wave-step's chain (LDS read, one dependent load, ~215 instructions at six waves per SIMD) plus its drain: "
-                            "0.79 of the issue slots; with launches in flight the drains overlap and the run sits at the issue limit (DESIGN.md §5)"}
+                    "note": "the kernel sits at the instruction-issue limit: 0.92 of the issue slots of a serialized 16-frame launch, its one drain included "
+                            "(0.79 for an 8-frame launch), 0.95 with launches in flight, where the drains overlap (DESIGN.md §5)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-3 profiling recipe (run on the GPU box through gpurun).  Kernel trace + separate PMC passes (never combined with
 # trace domains other than --kernel-trace); summaries are copied to profiles/ afterwards by scripts/summarize_profiles.py r03.
-# New this round: the PMC passes run on the REPORTED launch shape (8 frames per launch), serialized (--streams 1) and with
-# four launches in flight, next to the one-frame-per-launch passes that price traffic per frame.
+# New this round: the PMC passes run on the REPORTED launch shape (16 frames per launch), serialized (--streams 1) and with
+# two launches in flight, next to the one-frame-per-launch passes that price traffic per frame.
 set -e
 set -x
 R=$GRAFT_REPO_ROOT
@@ -13,12 +13,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt --
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt_serial -- $BENCH --steps 64 --warmup 32 --streams 1 > $R/gpurun_out/prof_kt_serial.log 2>&1
 C1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_ANY"
 C2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
-# (a) the reported shape, serialized: 8 frames per launch, one launch at a time
-P="--steps 32 --warmup 8 --streams 1 --frames-per-launch 8"
+# (a) the reported shape, serialized: 16 frames per launch, one launch at a time
+P="--steps 32 --warmup 16 --streams 1 --frames-per-launch 16"
 rocprofv3 --pmc $C1 --output-format csv -d $R/gpurun_out/prof_pmcA1 -- $BENCH $P > $R/gpurun_out/prof_pmcA1.log 2>&1
 rocprofv3 --pmc $C2 --output-format csv -d $R/gpurun_out/prof_pmcA2 -- $BENCH $P > $R/gpurun_out/prof_pmcA2.log 2>&1
-# (b) the reported shape, four launches in flight
-P="--steps 64 --warmup 32 --streams 4 --frames-per-launch 8"
+# (b) the reported shape, two launches in flight
+P="--steps 64 --warmup 32 --streams 2 --frames-per-launch 16"
 rocprofv3 --pmc $C1 --output-format csv -d $R/gpurun_out/prof_pmcB1 -- $BENCH $P > $R/gpurun_out/prof_pmcB1.log 2>&1
 rocprofv3 --pmc $C2 --output-format csv -d $R/gpurun_out/prof_pmcB2 -- $BENCH $P > $R/gpurun_out/prof_pmcB2.log 2>&1
 # (c) one frame per launch, every camera of the path once: traffic and instruction counts per frame

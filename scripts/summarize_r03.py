@@ -16,7 +16,7 @@ for name in ("prof_kt", "prof_kt_serial"):
     if last: S[name + "_bench_line"] = json.loads(last[-1])
 pmc = json.load(open(os.path.join(G, "prof_pmc_r03.json")))
 S["pmc"] = {"how": "separate rocprofv3 --pmc passes (scripts/prof_round3.sh); per k_trace_stack launch, median over the launches of the pass. "
-                   "A: 8 frames per launch, serialized.  B: 8 frames per launch, four launches in flight.  1/3/4/5: one frame per launch over the 32-camera path",
+                   "A: 16 frames per launch, serialized.  B: 16 frames per launch, two launches in flight.  1/3/4/5: one frame per launch over the 32-camera path",
             "passes": pmc}
 def med(p, c): return pmc[p]["counters"][c]["median_per_launch"]
 # ---- instruction issue: ONE figure with its spread
@@ -48,8 +48,9 @@ def weighted(idx):
 c_med, per_class = weighted(1); c_lo = weighted(0)[0]; c_hi = weighted(2)[0]
 insts = sum(med("prof_pmcA1", k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")) + med("prof_pmcA2", "SQ_INSTS_VMEM_WR")
 gfx_cycles = med("prof_pmcA2", "GRBM_GUI_ACTIVE") / 8.0              # summed over the 8 XCCs
-issue = {"instructions_per_launch_of_8_frames": insts, "instructions_per_frame": insts / 8,
-         "valu_per_frame": med("prof_pmcA1", "SQ_INSTS_VALU") / 8, "salu_per_frame": med("prof_pmcA1", "SQ_INSTS_SALU") / 8,
+FPL = 16        # frames per launch of passes A and B (scripts/prof_round3.sh)
+issue = {"instructions_per_launch_of_%d_frames" % FPL: insts, "instructions_per_frame": insts / FPL,
+         "valu_per_frame": med("prof_pmcA1", "SQ_INSTS_VALU") / FPL, "salu_per_frame": med("prof_pmcA1", "SQ_INSTS_SALU") / FPL,
          "static_mix_of_the_asm_step": dict(mix), "cycles_per_instruction_by_class_at_6_waves": {k: round(v, 3) for k, v in per_class.items()},
          "cycles_per_instruction_weighted": round(c_med, 3), "spread_p10_p90_over_simds": [round(c_lo, 3), round(c_hi, 3)],
          "gfx_cycles_per_launch": gfx_cycles, "simds": 1024,
@@ -59,7 +60,7 @@ issue = {"instructions_per_launch_of_8_frames": insts, "instructions_per_frame":
          "wave_wait_inst_fraction": round(med("prof_pmcA2", "SQ_WAIT_INST_ANY") / med("prof_pmcA1", "SQ_WAVE_CYCLES"), 4),
          "wave_active_fraction": round(med("prof_pmcA1", "SQ_ACTIVE_INST_ANY") / med("prof_pmcA1", "SQ_WAVE_CYCLES"), 4),
          "lane_utilisation_valu": round(med("prof_pmcA2", "SQ_THREAD_CYCLES_VALU") / (64 * med("prof_pmcA2", "SQ_ACTIVE_INST_VALU")), 4),
-         "how": "instructions of one serialized 8-frame launch (PMC pass A) / 1024 SIMDs x cycles per instruction, weighted with the static mix of the "
+         "how": "instructions of one serialized 16-frame launch (PMC pass A) / 1024 SIMDs x cycles per instruction, weighted with the static mix of the "
                 "hand-written step (step_asm.hip.h) from scripts/microbench/valu_issue at 6 waves per SIMD (waves grouped by the SIMD they ran on, each "
                 "SIMD's busy interval at the shader clock measured in the same run) / GFX-busy cycles of the launch (GRBM_GUI_ACTIVE / 8 XCCs)"}
 S["issue"] = issue
@@ -70,7 +71,7 @@ S["fabric_traffic_per_frame"] = {"fetch_size_raw": fetch_kb, "write_size_raw": w
 S["l2_hit_rate"] = med("prof_pmc3", "TCC_HIT_sum") / (med("prof_pmc3", "TCC_HIT_sum") + med("prof_pmc3", "TCC_MISS_sum"))
 json.dump(S, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
 rec = {"fabric_bytes_per_frame": fabric, "l2_hit_rate": round(S["l2_hit_rate"], 4), "tcc_miss_per_frame": med("prof_pmc3", "TCC_MISS_sum"),
-       "source": "profiles/r03_summary.json (PMC passes of scripts/prof_round3.sh: traffic from one-frame launches over the 32-camera path, instruction issue from serialized 8-frame launches)",
+       "source": "profiles/r03_summary.json (PMC passes of scripts/prof_round3.sh: traffic from one-frame launches over the 32-camera path, instruction issue from serialized 16-frame launches)",
        "issue": {k: issue[k] for k in ("instructions_per_frame", "valu_per_frame", "salu_per_frame", "cycles_per_instruction_weighted", "spread_p10_p90_over_simds",
                                        "issue_utilisation", "issue_utilisation_spread", "wave_wait_fraction", "wave_active_fraction", "lane_utilisation_valu")}}
 json.dump({"c3_1080p_depth12_4x1x4_shadow": rec}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
