@@ -24,6 +24,8 @@
  *   svo_world_index*     <- World::index / index_float             src/World.cpp:276-293,323-332
  *   svo_chunk_write/read <- Ocroot::write / Ocroot::read           src/Octree.cpp:178-201
  *   svo_world_shift      <- World::shift                           src/World.cpp:334-378
+ *   svo_world_edit_box   <- Ocroot::build / destroy / replace + World::modify   src/Octree.cpp:203-443, src/World.cpp:268-274
+ *                           (the caller's pattern: src/Main.cpp:340-367)
  *   svo_shade(_packed)   <- lighting of fragment main               shaders/World.Fragment.glsl:63-138,180-197
  *
  * Conventions
@@ -38,7 +40,7 @@
  *   - svo_trace* launches of one world may overlap on different streams (frames in flight); each
  *     launch owns a private work-cursor slot from a 64-entry ring, and a launch that comes round
  *     to a slot still in use is ordered on the device behind that earlier launch;
- *   - svo_world_update / svo_world_shift / svo_world_upload are ordered behind every launch issued
+ *   - svo_world_update / svo_world_shift / svo_world_edit_box / svo_world_upload are ordered behind every launch issued
  *     before them on any stream (they drain the device before touching HBM, as World::modify is
  *     ordered on the GL queue) and have completed when they return: launches issued afterwards see
  *     the new world, launches issued before saw the old one, none sees a mixture.
@@ -266,6 +268,17 @@ int svo_world_update(svo_world *, int chunk, const svo_chunk_desc *desc,
  * On an uploaded world the plane is generated on the device the pools live on and installed device-to-device (host
  * copies of those chunks are made on request, svo_world_chunk); otherwise on the host. */
 int svo_world_shift(svo_world *, const int offset[3]);
+
+/* Ocroot::build / destroy / replace (src/Octree.cpp:203-443) followed by World::modify (src/World.cpp:268-274) on chunk
+ * `chunk` of an UPLOADED world, run on the device the pools live on: the closed box [lo, hi] is filled with `material`
+ * where the chunk is empty (SVO_EDIT_BUILD), emptied (SVO_EDIT_DESTROY), or emptied and then filled (SVO_EDIT_REPLACE).
+ * Node blocks and bricks are appended in the reference's depth-first order, so the pools equal what the reference's
+ * edit leaves, index for index; its storage sizes double by the reference's rule.  The box is in world coordinates and may
+ * extend beyond the chunk (the reference's caller applies the same cube to every chunk it overlaps, src/Main.cpp:322-338).
+ * Nothing visits the host; a host copy of the chunk is made again on request (svo_world_chunk).
+ * SVO_ERR_NOT_UPLOADED on a world that is not resident. */
+enum { SVO_EDIT_BUILD = 0, SVO_EDIT_DESTROY = 1, SVO_EDIT_REPLACE = 2 };
+int svo_world_edit_box(svo_world *, int chunk, int op, const float lo[3], const float hi[3], uint16_t material);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 

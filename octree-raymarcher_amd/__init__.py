@@ -44,6 +44,7 @@ ERR_NAMES = {0: "SVO_OK", -1: "SVO_ERR_INVALID_ARG", -2: "SVO_ERR_NO_DEVICE", -3
              -4: "SVO_ERR_MALFORMED_TREE", -5: "SVO_ERR_NOT_UPLOADED", -6: "SVO_ERR_UNSUPPORTED", -7: "SVO_ERR_HIP"}
 EMPTY, LEAF, BRANCH, TWIG = 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_LITERAL, KERNEL_STACK = 0, 1, 2
+EDIT_BUILD, EDIT_DESTROY, EDIT_REPLACE = 0, 1, 2     # svo_world_edit_box
 HIT_FLAG, SHADOW_TRACED, SHADOWED, FACE_NORMAL, ERR_FLAG = 1, 2, 4, 8, 1 << 15
 NORMAL_CUBE, NORMAL_FACE = 0, 1
 CELL_NONE = 0xFF
@@ -126,7 +127,7 @@ MAX_FRAMES = 16                     # SVO_MAX_FRAMES
 ABI_SYMBOLS = [
     "svo_world_generate", "svo_world_create", "svo_world_info_get", "svo_world_chunk", "svo_world_destroy",
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
-    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_shade", "svo_shade_packed", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
+    "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_world_edit_box", "svo_shade", "svo_shade_packed", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
     "svo_tile_order", "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
     "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
@@ -135,6 +136,7 @@ ABI_SYMBOLS = [
 _P = C.c_void_p
 lib.svo_last_error.restype = C.c_char_p
 lib.svo_abi_version.restype = C.c_int
+lib.svo_world_edit_box.argtypes = [_P, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint16]
 lib.svo_world_generate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(TerrainParams), C.POINTER(_P)]
 lib.svo_world_create.argtypes = [C.POINTER(ChunkDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]
 lib.svo_world_info_get.argtypes = [_P, C.POINTER(WorldInfo)]
@@ -423,6 +425,11 @@ class World:
         d.twig, d.twigs = twig.ctypes.data_as(C.POINTER(C.c_uint16)), twig.size // 64
         _check(lib.svo_world_update(self._h, chunk, C.byref(d), tree_range[0], tree_range[1], twig_range[0], twig_range[1],
                                     1 if realloc else 0), "svo_world_update")
+
+    def edit_box(self, chunk: int, op: int, lo, hi, material: int = 0):
+        """Ocroot::build / destroy / replace + World::modify on the device (svo_world_edit_box); op = EDIT_BUILD / EDIT_DESTROY / EDIT_REPLACE."""
+        _check(lib.svo_world_edit_box(self._h, int(chunk), int(op), (C.c_float * 3)(*[float(v) for v in lo]),
+                                      (C.c_float * 3)(*[float(v) for v in hi]), C.c_uint16(int(material))), "svo_world_edit_box")
 
     def shift(self, offset):
         """World::shift (src/World.cpp:334-378): slide the grid one chunk along one axis."""

@@ -299,25 +299,28 @@ struct DevicePyramidBuilder {
     }
 };
 
-// ---- Ocroot::build on the device (src/Octree.cpp:320-436; the host restatement is terrain.cpp's Filler) ------------------
-// The reference fills depth-first in child-slot order and APPENDS as it goes: an EMPTY node the region cuts becomes a BRANCH
-// whose 8-block lands at the pool's tail (a "split"), or - at the brick level - a TWIG whose brick lands at the brick pool's
-// tail.  So the index a new block / brick gets is the number of splits / new bricks that precede it in depth-first preorder.
-// Three level-synchronous sweeps over the nodes the region touches give exactly that:
+// ---- Ocroot::build / Ocroot::destroy on the device (src/Octree.cpp:320-436 / :203-318; terrain.cpp's Filler is build's host twin) ----
+// The reference edits depth-first in child-slot order and APPENDS as it goes: a node the region cuts - EMPTY for build, LEAF for
+// destroy - becomes a BRANCH whose 8-block lands at the pool's tail (a "split"), or - at the brick level - a TWIG whose brick
+// lands at the brick pool's tail.  So the index a new block / brick gets is the number of splits / new bricks that precede it
+// in depth-first preorder.  Three level-synchronous sweeps over the nodes the region touches give exactly that:
 //   A (top-down)   k_fill_classify: what the visit does at each node (its action), the 8 children of every node the visit
 //                  descends into appended to the next level's list (any order: the lists only link parents to children)
 //   B (bottom-up)  k_fill_count: splits / new bricks in each node's subtree
 //   C (top-down)   k_fill_number: preorder prefix of those counts = each event's index; node words written, new blocks
-//                  initialised EMPTY, brick edits listed for k_brick_fill
-// A node the fill creates has no slot until sweep C: its list entry carries FILL_VIRTUAL until its parent numbers it.
-enum FillAction : uint32_t { FILL_NONE = 0, FILL_MAKE_LEAF, FILL_NEW_BRICK, FILL_SPLIT, FILL_BRICK, FILL_DESCEND };
-constexpr uint32_t FILL_VIRTUAL = 0xFFFFFFFFu;
+//                  initialised (EMPTY for build, the split LEAF's material for destroy), brick edits listed for k_brick_edit
+// A node the edit creates has no slot until sweep C: until its parent numbers it, its list entry carries FILL_VIRTUAL and what
+// the reference would read there (EMPTY, or LEAF + material).
+enum FillAction : uint32_t { FILL_NONE = 0, FILL_SET, FILL_NEW_BRICK, FILL_SPLIT, FILL_BRICK, FILL_DESCEND };
+enum EditOp : uint32_t { EDIT_BUILD = 0, EDIT_DESTROY = 1 };
+constexpr uint32_t FILL_VIRTUAL = 0x80000000u, FILL_VIRTUAL_LEAF = 0x00010000u;
 
 struct FillArgs {
     float rlo[3], rhi[3];       // the region (closed box)
     float edge;                 // node edge at this level
-    uint32_t level, maxlevel;   // maxlevel = depth - TWIG_LEVELS: EMPTY nodes there become bricks
-    uint32_t material;
+    uint32_t level, maxlevel;   // maxlevel = depth - TWIG_LEVELS: nodes cut there become bricks
+    uint32_t material;          // build: what the region is filled with
+    uint32_t op;                // EDIT_BUILD / EDIT_DESTROY
 };
 
 // act[i] = action | kids << 8 (kids = index of the node's child block in the next level's list)
@@ -332,17 +335,21 @@ __global__ __launch_bounds__(256) void k_fill_classify(const Cell *cells, uint32
     // cubesIntersect on closed boxes (src/Traverse.cpp:173-178), the host Filler's expressions
     const bool touch = hx >= F.rlo[0] && hy >= F.rlo[1] && hz >= F.rlo[2] && F.rhi[0] >= e.x && F.rhi[1] >= e.y && F.rhi[2] >= e.z;
     if (touch) {
-        if (e.slot != FILL_VIRTUAL) word = tree[e.slot];
-        switch (node_type(word)) {
-        case LEAF: break;
-        case EMPTY: {
-            // cubeIsInside (src/Traverse.cpp:180-185)
-            const bool inside = e.x >= F.rlo[0] && e.y >= F.rlo[1] && e.z >= F.rlo[2] && F.rhi[0] >= hx && F.rhi[1] >= hy && F.rhi[2] >= hz;
-            a = inside ? FILL_MAKE_LEAF : (F.level == F.maxlevel ? FILL_NEW_BRICK : FILL_SPLIT);
-            break;
-        }
-        case TWIG: a = FILL_BRICK; break;
-        default: a = FILL_DESCEND; break;
+        if (!(e.slot & FILL_VIRTUAL)) word = tree[e.slot];
+        else if (e.slot & FILL_VIRTUAL_LEAF) word = node_make(LEAF, e.slot & 0xFFFFu);
+        // cubeIsInside (src/Traverse.cpp:180-185)
+        const bool inside = e.x >= F.rlo[0] && e.y >= F.rlo[1] && e.z >= F.rlo[2] && F.rhi[0] >= hx && F.rhi[1] >= hy && F.rhi[2] >= hz;
+        const uint32_t type = node_type(word);
+        if (F.op == EDIT_BUILD) {           // buildCube, src/Octree.cpp:338-430
+            if (type == EMPTY) a = inside ? FILL_SET : (F.level == F.maxlevel ? FILL_NEW_BRICK : FILL_SPLIT);
+            else if (type == TWIG) a = FILL_BRICK;
+            else if (type == BRANCH) a = FILL_DESCEND;
+        } else {                            // destroyCube, src/Octree.cpp:220-312: whatever lies inside goes, LEAF nodes the region cuts are split
+            if (type == EMPTY) a = FILL_NONE;
+            else if (inside) a = FILL_SET;
+            else if (type == LEAF) a = F.level == F.maxlevel ? FILL_NEW_BRICK : FILL_SPLIT;
+            else if (type == TWIG) a = FILL_BRICK;
+            else a = FILL_DESCEND;
         }
     }
     uint32_t kids = 0;
@@ -350,11 +357,12 @@ __global__ __launch_bounds__(256) void k_fill_classify(const Cell *cells, uint32
         kids = atomicAdd(&counters[0], 1u);
         const float half = F.edge * 0.5f;
         const uint32_t first = node_offset(word);
+        const uint32_t inherit = FILL_VIRTUAL | (F.op == EDIT_DESTROY ? FILL_VIRTUAL_LEAF | (node_offset(word) & 0xFFFFu) : 0u);
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c) {
             const float ox = (c & 1) ? 1.0f : 0.0f, oy = (c & 2) ? 1.0f : 0.0f, oz = (c & 4) ? 1.0f : 0.0f;
             Cell ch; ch.x = e.x + ox * half; ch.y = e.y + oy * half; ch.z = e.z + oz * half;
-            ch.slot = a == FILL_DESCEND ? first + c : FILL_VIRTUAL;
+            ch.slot = a == FILL_DESCEND ? first + c : inherit;
             next[8 * (uint64_t)kids + c] = ch;
         }
     }
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fill_count(const uint32_t *act, uint32_
     cnt[i] = v;
 }
 
-struct DevBrickOp { uint64_t brick; float x, y, z, voxel; };
+struct DevBrickOp { uint64_t brick; float x, y, z, voxel; uint32_t fresh, init; };     // fresh: a brick this edit appends, every cell starts as `init`
 
 // On entry cnt[i] = {splits, new bricks} that precede node i's own events in preorder (the root: 0, 0); the node's children
 // get theirs (their subtree counts are replaced by the running prefix), new nodes get their slots, node words are written.
@@ -388,25 +396,29 @@ __global__ __launch_bounds__(256) void k_fill_number(Cell *cells, uint32_t n, Fi
     if (i >= n) return;
     const uint32_t a = act[i] & 255u, kids = act[i] >> 8;
     if (a == FILL_NONE) return;
-    const Cell e = cells[i];
+    const Cell e = cells[i];                // (its slot is a real one by now: the parent's turn came a launch earlier)
     const uint2 base = cnt[i];
     switch (a) {
-    case FILL_MAKE_LEAF:
-        tree[e.slot] = node_make(LEAF, F.material);
+    case FILL_SET:
+        tree[e.slot] = F.op == EDIT_BUILD ? node_make(LEAF, F.material) : node_make(EMPTY, 0);
         break;
     case FILL_NEW_BRICK:
     case FILL_BRICK: {
-        uint32_t brick;
-        if (a == FILL_NEW_BRICK) { brick = twigs0 + base.y; tree[e.slot] = node_make(TWIG, brick); }
-        else brick = node_offset(tree[e.slot]);
-        DevBrickOp op; op.brick = brick; op.x = e.x; op.y = e.y; op.z = e.z; op.voxel = F.edge / (float)(1 << TWIG_LEVELS);
+        const uint32_t word = tree[e.slot];
+        DevBrickOp op;
+        op.fresh = a == FILL_NEW_BRICK ? 1u : 0u;
+        op.init = F.op == EDIT_DESTROY ? node_offset(word) & 0xFFFFu : 0u;        // Octwig(material of the LEAF that is cut) / Octwig(0)
+        if (a == FILL_NEW_BRICK) { op.brick = twigs0 + base.y; tree[e.slot] = node_make(TWIG, (uint32_t)op.brick); }
+        else op.brick = node_offset(word);
+        op.x = e.x; op.y = e.y; op.z = e.z; op.voxel = F.edge / (float)(1 << TWIG_LEVELS);
         ops[atomicAdd(op_cursor, 1u)] = op;
         break;
     }
     default: {
         uint2 run = base;
-        uint32_t first = 0;
+        uint32_t first = 0, inherit = node_make(EMPTY, 0);
         if (a == FILL_SPLIT) {
+            if (F.op == EDIT_DESTROY) inherit = tree[e.slot];                     // 8 LEAF children of the same material
             first = trees0 + 8u * base.x;
             tree[e.slot] = node_make(BRANCH, first);
             run.x += 1;
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(256) void k_fill_number(Cell *cells, uint32_t n, Fi
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c) {
             const uint64_t k = 8 * (uint64_t)kids + c;
-            if (a == FILL_SPLIT) { tree[first + c] = node_make(EMPTY, 0); next[k].slot = first + c; }
+            if (a == FILL_SPLIT) { tree[first + c] = inherit; next[k].slot = first + c; }
             const uint2 sub = cnt_next[k];
             cnt_next[k] = run;
             run.x += sub.x; run.y += sub.y;
@@ -423,21 +435,25 @@ __global__ __launch_bounds__(256) void k_fill_number(Cell *cells, uint32_t n, Fi
     }
 }
 
-// Ocroot::build on bricks that live in the pool: cell empty and its voxel box touches the region -> material
-// (src/Octree.cpp:395-410; cubesIntersect on closed boxes, the host Filler's expressions).
-__global__ __launch_bounds__(256) void k_brick_fill(uint16_t *twig, const DevBrickOp *ops, uint32_t n, uint64_t first_brick,
+// The brick half of both edits (src/Octree.cpp:395-410 / :285-300): build - a cell that is empty and whose voxel box touches the
+// region takes the material; destroy - a cell whose voxel box touches the region is emptied (cubesIntersect on closed boxes,
+// the host Filler's expressions).
+__global__ __launch_bounds__(256) void k_brick_edit(uint16_t *twig, const DevBrickOp *ops, uint32_t n, uint32_t edit,
                                                     float rlx, float rly, float rlz, float rhx, float rhy, float rhz, uint32_t material)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n * 64u) return;
     const DevBrickOp op = ops[i >> 6];
     const uint32_t cell = i & 63u, cx = cell & 3u, cy = (cell >> 2) & 3u, cz = cell >> 4;
-    uint16_t *p = twig + (first_brick + op.brick) * TWIG_WORDS + cell;
-    if (*p != 0) return;
+    uint16_t *p = twig + op.brick * TWIG_WORDS + cell;
+    const uint32_t before = op.fresh ? op.init : (uint32_t)*p;
     const float lx = op.x + (float)cx * op.voxel, ly = op.y + (float)cy * op.voxel, lz = op.z + (float)cz * op.voxel;
     const float hx = lx + op.voxel, hy = ly + op.voxel, hz = lz + op.voxel;
     const bool touch = hx >= rlx && hy >= rly && hz >= rlz && rhx >= lx && rhy >= ly && rhz >= lz;
-    if (touch) *p = (uint16_t)material;
+    uint32_t after = before;
+    if (edit == EDIT_BUILD) { if (before == 0u && touch) after = material; }
+    else if (touch) after = 0u;
+    if (op.fresh || after != before) *p = (uint16_t)after;
 }
 
 struct DeviceFiller {
@@ -448,10 +464,11 @@ struct DeviceFiller {
     uint32_t *h_counters = nullptr; // pinned
     ~DeviceFiller() { if (h_counters) (void)hipHostFree(h_counters); }
 
-    // The fill of region [lo, hi] with `material` applied to the chunk grow() left in `tree` (trees nodes) and `twig` (twigs
-    // bricks); both buffers grow as needed, c's counts and capacities follow the reference's bookkeeping.
+    // Ocroot::build (edit = EDIT_BUILD: region [lo, hi] filled with `material`) or Ocroot::destroy (EDIT_DESTROY: emptied) applied
+    // to the chunk in `tree` (trees nodes) and `twig` (twigs bricks); both buffers grow as needed, c's capacities follow the
+    // reference's doubling.
     int fill(ChunkPools &c, const float lo[3], const float hi[3], uint32_t material, DevBuf<uint32_t> &tree, uint64_t &trees,
-             DevBuf<uint16_t> &twig, uint64_t &twigs, hipStream_t s)
+             DevBuf<uint16_t> &twig, uint64_t &twigs, hipStream_t s, uint32_t edit = EDIT_BUILD)
     {
         int rc;
         const uint32_t maxlevel = c.depth - TWIG_LEVELS;
@@ -461,7 +478,7 @@ struct DeviceFiller {
         BUILD_TRY(hipMemsetAsync(counters.p, 0, 80 * sizeof(uint32_t), s));
         FillArgs F{};
         for (int a = 0; a < 3; ++a) { F.rlo[a] = lo[a]; F.rhi[a] = hi[a]; }
-        F.maxlevel = maxlevel; F.material = material;
+        F.maxlevel = maxlevel; F.material = material; F.op = edit;
         // sweep A
         if ((rc = lv[0].cells.reserve(1, false, s)) != SVO_OK) return rc;
         const Cell root = { c.position[0], c.position[1], c.position[2], 0u };
@@ -514,7 +531,7 @@ struct DeviceFiller {
                                (uint32_t)trees, (uint32_t)twigs, tree.p, ops.p, counters.p + 64);
         }
         if (brick_edits)
-            hipLaunchKernelGGL(k_brick_fill, dim3(blocks_for((uint64_t)brick_edits * 64, 256)), dim3(256), 0, s, twig.p, ops.p, brick_edits, (uint64_t)0,
+            hipLaunchKernelGGL(k_brick_edit, dim3(blocks_for((uint64_t)brick_edits * 64, 256)), dim3(256), 0, s, twig.p, ops.p, brick_edits, edit,
                                F.rlo[0], F.rlo[1], F.rlo[2], F.rhi[0], F.rhi[1], F.rhi[2], material);
         BUILD_TRY(hipGetLastError());
         // capacity bookkeeping of the reference's appends (src/Octree.cpp:349-351,365-368; terrain.cpp's Filler)
@@ -720,6 +737,43 @@ int shift_world_resident(svo_world &w, int axis, int sign)
 {
     try { return shift_world_resident_impl(w, axis, sign); }
     catch (const std::bad_alloc &) { set_error("svo_world_shift: out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
+}
+
+// Ocroot::build / destroy / replace + World::modify (src/Octree.cpp:203-443, src/World.cpp:268-274; the caller's pattern is
+// src/Main.cpp:340-367) on an uploaded world, without the host: the chunk's pools are copied out of the packed pools, edited by
+// the three sweeps above and installed again with svo_world_update's slot logic.  A host copy of the chunk, if there was one,
+// is dropped (svo_world_chunk fetches the edited pools on request).
+static int edit_box_resident_impl(svo_world &w, int chunk, int op, const float lo[3], const float hi[3], uint32_t material)
+{
+    BUILD_TRY(hipSetDevice(w.device));
+    BUILD_TRY(hipDeviceSynchronize());              // ordered behind every launch issued before it, like svo_world_update
+    hipStream_t s = nullptr;
+    const ChunkPools &c = w.chunks[(size_t)chunk];
+    const DevChunk &e = w.table[(size_t)chunk];
+    uint64_t trees = c.tree_count(), twigs = c.twig_count();
+    DevBuf<uint32_t> tree;
+    DevBuf<uint16_t> twig;
+    int rc;
+    if ((rc = tree.reserve(trees + 1024, false, s)) != SVO_OK || (rc = twig.reserve((twigs + 16) * TWIG_WORDS, false, s)) != SVO_OK) return rc;
+    BUILD_TRY(hipMemcpyAsync(tree.p, w.d_tree + e.tree_off, trees * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (twigs) BUILD_TRY(hipMemcpyAsync(twig.p, w.d_twig + e.twig_off * TWIG_WORDS, twigs * TWIG_WORDS * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+    ChunkPools meta;
+    std::memcpy(meta.position, c.position, sizeof meta.position);
+    meta.size = c.size; meta.depth = c.depth;
+    meta.tree_capacity = c.tree_capacity; meta.twig_capacity = c.twig_capacity;
+    DeviceFiller filler;
+    if (op == SVO_EDIT_DESTROY || op == SVO_EDIT_REPLACE)
+        if ((rc = filler.fill(meta, lo, hi, material, tree, trees, twig, twigs, s, EDIT_DESTROY)) != SVO_OK) return rc;
+    if (op == SVO_EDIT_BUILD || op == SVO_EDIT_REPLACE)
+        if ((rc = filler.fill(meta, lo, hi, material, tree, trees, twig, twigs, s, EDIT_BUILD)) != SVO_OK) return rc;
+    meta.trees_on_device = trees; meta.twigs_on_device = twigs;
+    return install_resident_chunk(w, chunk, meta, tree.p, twig.p);
+}
+
+int edit_box_resident(svo_world &w, int chunk, int op, const float lo[3], const float hi[3], uint32_t material)
+{
+    try { return edit_box_resident_impl(w, chunk, op, lo, hi, material); }
+    catch (const std::bad_alloc &) { set_error("svo_world_edit_box: out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }
 }
 
 int generate_world_resident(svo_world &w, int device)

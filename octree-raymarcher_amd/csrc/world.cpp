@@ -231,6 +231,14 @@ int svo_world_shift(svo_world *w, const int offset[3])
     return SVO_OK;
 }
 
+int svo_world_edit_box(svo_world *w, int chunk, int op, const float lo[3], const float hi[3], uint16_t material)
+{
+    if (!w || !lo || !hi || chunk < 0 || chunk >= (int)w->chunks.size() || op < SVO_EDIT_BUILD || op > SVO_EDIT_REPLACE) { set_error("svo_world_edit_box: bad argument"); return SVO_ERR_INVALID_ARG; }
+    for (int a = 0; a < 3; ++a) if (!(lo[a] <= hi[a])) { set_error("svo_world_edit_box: lo must not exceed hi (and neither may be NaN)"); return SVO_ERR_INVALID_ARG; }
+    if (w->device < 0) { set_error("svo_world_edit_box: the world is not uploaded (edit the host pools and pass them to svo_world_update instead)"); return SVO_ERR_NOT_UPLOADED; }
+    return edit_box_resident(*w, chunk, op, lo, hi, material);
+}
+
 int svo_world_info_get(const svo_world *w, svo_world_info *o)
 {
     if (!w || !o) return SVO_ERR_INVALID_ARG;

@@ -63,6 +63,8 @@ int  install_resident_chunk(svo_world &w, int chunk, const ChunkPools &meta, con
 int  rebuild_wide_chunk(svo_world &w, int chunk, void *stream);
 // builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
 int  generate_world_resident(svo_world &w, int device);
+// builder.hip: Ocroot::build / destroy / replace + World::modify on an uploaded world
+int  edit_box_resident(svo_world &w, int chunk, int op, const float lo[3], const float hi[3], uint32_t material);
 // builder.hip: World::shift's entering plane generated on the device the world is uploaded to
 int  shift_world_resident(svo_world &w, int axis, int sign);
 } // namespace svo

@@ -1,0 +1,121 @@
+"""Box edits on the device (svo_world_edit_box; csrc/builder.hip: DeviceFiller): Ocroot::build / destroy / replace followed by
+World::modify (src/Octree.cpp:203-443, src/World.cpp:268-274) without the host.  After every edit the chunk's pools must equal,
+index for index, what the oracle's restatement of the reference's recursive edits leaves (orc_build / orc_destroy append blocks and
+bricks depth-first), and the march over the edited world must equal the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_gbuffer_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_edit(oracle, O, chunk, op, lo, hi, material):
+    dt, dw = oracle.Delta(), oracle.Delta()
+    root = C.byref(O.w.chunk[chunk])
+    if op in (1, 2):
+        oracle.lib.orc_destroy(root, oracle.vec3(lo), oracle.vec3(hi), C.byref(dt), C.byref(dw))
+    if op in (0, 2):
+        oracle.lib.orc_build(root, oracle.vec3(lo), oracle.vec3(hi), material, C.byref(dt), C.byref(dw))
+
+
+def pools_equal(O, D, n, what):
+    for i in range(n):
+        a, b = O.chunk(i), D.chunk(i, copy=False)
+        assert a["tree"].size == b["tree"].size and a["twig"].size == b["twig"].size, f"{what}: chunk {i} pool sizes differ"
+        assert np.array_equal(a["tree"], b["tree"]), f"{what}: chunk {i} node words differ"
+        assert np.array_equal(a["twig"], b["twig"]), f"{what}: chunk {i} bricks differ"
+
+
+EDITS = [
+    # (op, chunks, lo, hi, material): the reference's caller applies one cube to every chunk it overlaps (src/Main.cpp:322-338)
+    (0, (0,), (20, 60, 20), (70, 110, 50), 5),                  # build in the air above the terrain
+    (1, (0,), (0, 0, 0), (128, 45, 30), 0),                     # destroy a slab through terrain and water
+    (2, (0, 1), (100.3, 10.7, 40.1), (150.9, 70.2, 90.6), 5),   # replace across the chunk seam, off the lattice
+    (0, (1,), (130.0, 0.0, 0.0), (131.0, 128.0, 1.0), 7),       # a voxel-wide column
+    (1, (1,), (128, 0, 0), (256, 128, 128), 0),                 # destroy a whole chunk: its root ends EMPTY... (a BRANCH inside the box is cut off)
+    (0, (1,), (128, 0, 0), (256, 128, 128), 3),                 # ... and build it solid again: the root becomes one LEAF
+    (1, (1,), (180.25, 60.5, 60.125), (181.0, 61.0, 61.5), 0),  # carve a few voxels out of the solid chunk: splits all the way down
+    (0, (0,), (500, 500, 500), (600, 600, 600), 5),             # does not touch the chunk: nothing changes
+    (2, (0,), (63.99, 5.99, 63.99), (64.01, 6.01, 64.01), 2),   # straddles a node corner and the water plane
+]
+
+
+def test_edit_box_equals_the_oracles_edits(svo, oracle):
+    O = oracle.OracleWorld.generate(2, 1, 1, 128, 7)
+    D = svo.World.generate(2, 1, 1, 128, 7, build_device=0)
+    o, d = random_rays(np.random.default_rng(21), 20000, (0, 0, 0), (256, 128, 128))
+    prm = oracle.make_params(shadow=True)
+    for k, (op, chunks, lo, hi, mat) in enumerate(EDITS):
+        for i in chunks:
+            oracle_edit(oracle, O, i, op, lo, hi, mat)
+            D.edit_box(i, op, lo, hi, mat)
+        want = O.trace_rays(o, d, params=prm, threads=8)
+        for kern in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+            assert_gbuffer_equal(D.chunkmarch(o, d, shadow=True, kernel=kern), want, f"edit {k} / kernel {kern}")
+        if k % 2 == 0 or k == len(EDITS) - 1:                   # (every other edit runs on a chunk whose host copy was never made)
+            pools_equal(O, D, 2, f"after edit {k}")
+    D.destroy()
+
+
+@pytest.mark.parametrize("depth,seed", [(6, 1), (9, 2)])
+def test_random_edit_sequences(svo, oracle, depth, seed):
+    """Forty random edits of all three kinds - boxes from a voxel to half a chunk, on and off the lattice - on one chunk: pools
+    equal the oracle's after every tenth edit and at the end (slots are outgrown and the world re-packed on the way)."""
+    rng = np.random.default_rng(seed)
+    O = oracle.OracleWorld.generate(1, 1, 1, 128, depth)
+    D = svo.World.generate(1, 1, 1, 128, depth, build_device=0)
+    voxel = 128.0 / (1 << depth)
+    for k in range(40):
+        op = int(rng.integers(0, 3))
+        edge = float(rng.choice([voxel, 3 * voxel, 7.3, 20.0, 64.0]))
+        lo = rng.uniform(-4, 120, 3)
+        if rng.random() < 0.5:
+            lo = np.floor(lo / voxel) * voxel                    # on the voxel lattice: closed boxes touch their neighbours
+        hi = lo + edge * rng.uniform(0.3, 1.0, 3)
+        mat = int(rng.integers(1, 8))
+        oracle_edit(oracle, O, 0, op, lo.astype(np.float32), hi.astype(np.float32), mat)
+        D.edit_box(0, op, lo.astype(np.float32), hi.astype(np.float32), mat)
+        if k % 10 == 9:
+            pools_equal(O, D, 1, f"depth {depth}, after edit {k}")
+    o, d = random_rays(np.random.default_rng(seed + 100), 20000, (0, 0, 0), (128, 128, 128))
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    for kern in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(D.chunkmarch(o, d, shadow=True, kernel=kern), want, f"depth {depth} / kernel {kern}")
+    D.destroy()
+
+
+def test_edit_box_argument_checks(svo):
+    H = svo.World.generate(1, 1, 1, 128, 4)                     # not uploaded
+    with pytest.raises(svo.SvoError) as e:
+        H.edit_box(0, svo.EDIT_BUILD, (0, 0, 0), (1, 1, 1), 5)
+    assert e.value.code == -5
+    H.upload(0)
+    for bad in [dict(chunk=1, op=0, lo=(0, 0, 0), hi=(1, 1, 1)), dict(chunk=0, op=3, lo=(0, 0, 0), hi=(1, 1, 1)),
+                dict(chunk=0, op=0, lo=(2, 0, 0), hi=(1, 1, 1)), dict(chunk=0, op=0, lo=(float("nan"), 0, 0), hi=(1, 1, 1))]:
+        with pytest.raises(svo.SvoError):
+            H.edit_box(bad["chunk"], bad["op"], bad["lo"], bad["hi"], 5)
+    H.edit_box(0, svo.EDIT_BUILD, (10, 100, 10), (20, 110, 20), 5)    # a host-built, uploaded world takes the edit too
+    H.destroy()
+
+
+def test_edit_box_on_a_benchmark_chunk(svo):
+    """A depth-12 chunk of C3's world (6 M nodes, 2 M bricks): the reference's interactive edits (a 1/8-chunk cube, src/Main.cpp:340-367)
+    on the device; destroy then build of the same box must leave what replace leaves; the time is printed."""
+    import time
+    W = svo.World.generate(2, 1, 2, 128, 12, build_device=0)
+    R = svo.World.generate(2, 1, 2, 128, 12, build_device=0)
+    lo, hi = (40.0, 0.0, 40.0), (56.0, 16.0, 56.0)
+    t0 = time.time(); W.edit_box(0, svo.EDIT_DESTROY, lo, hi); t1 = time.time(); W.edit_box(0, svo.EDIT_BUILD, lo, hi, 5); t2 = time.time()
+    R.edit_box(0, svo.EDIT_REPLACE, lo, hi, 5); t3 = time.time()
+    print(f"\ndepth-12 chunk: destroy {t1 - t0:.4f} s, build {t2 - t1:.4f} s, replace {t3 - t2:.4f} s")
+    a, b = W.chunk(0, copy=False), R.chunk(0, copy=False)
+    assert np.array_equal(a["tree"], b["tree"]) and np.array_equal(a["twig"], b["twig"])
+    cam = svo.make_camera((48.3, 60.0, 20.0), (0.0, -0.7, 0.714), (0.0, 1.0, 0.0), 60.0, 320, 180)
+    ga, gb = W.draw(cam, shadow=True), R.draw(cam, shadow=True)
+    assert_gbuffer_equal(ga, gb, "destroy + build against replace")
+    assert (ga["material"] == 5).sum() > 100                    # the built cube is in view
+    assert t3 - t0 < 1.0
+    W.destroy(); R.destroy()
