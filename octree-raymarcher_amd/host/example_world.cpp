@@ -1,4 +1,4 @@
-// example_world.cpp — the reference's main-loop calls (src/Main.cpp:80-81,222,314-319) against svo::World.
+// example_world.cpp — the reference's main-loop calls (src/Main.cpp:80-81,222,314-319,340-367) against svo::World.
 //   g++ -std=c++17 -I. example_world.cpp -L.. -lsvo_amd -Wl,-rpath,'$ORIGIN/..' -o example_world
 #include <cstdio>
 #include "svo_world.hpp"
@@ -28,6 +28,19 @@ int main(int argc, char **argv)
         svo::vec3 sigma = { 0.0f, 0.0f, 0.0f };
         const bool hit = svo::chunkmarch({ 250.3f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, &world, &sigma);
         std::printf("hits %zu shadowed %zu cursor %s (%.3f %.3f %.3f)\n", hits, shadowed, hit ? "hit" : "miss", sigma.x, sigma.y, sigma.z);
+        // Main.cpp:350-357 build(): a cube of material 5 at the cursor, in every chunk it overlaps; then the edit cursor again
+        if (hit) {
+            const svo::vec3 cmin = { sigma.x - 4.0f, sigma.y, sigma.z - 4.0f }, cmax = { sigma.x + 4.0f, sigma.y + 8.0f, sigma.z + 4.0f };
+            for (int i = 0; i < world.volume; ++i) world.build(i, cmin, cmax, 5);
+            svo::vec3 again = { 0.0f, 0.0f, 0.0f };
+            const bool hit2 = svo::chunkmarch({ 250.3f, 150.0f, -40.0f }, { 0.0f, -0.5f, 0.866f }, &world, &again);
+            if (!hit2 || !(again.y > sigma.y)) { std::fprintf(stderr, "build: the cursor ray does not stop on the new cube\n"); return 4; }
+            for (int i = 0; i < world.volume; ++i) world.destroy(i, cmin, cmax);       // Main.cpp:340-347 destroy()
+            world.shift({ 1, 0, 0 });                    // World::shift, src/World.cpp:334-378
+            world.draw(cam, gbuffer, /*shadow=*/true);
+            svo_stream_synchronize(nullptr);
+            std::printf("after build / destroy / shift: cursor moved up by %.3f\n", again.y - sigma.y);
+        }
         return hits > 0 ? 0 : 1;
     } catch (const svo::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code, e.what());

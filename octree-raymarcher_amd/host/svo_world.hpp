@@ -148,6 +148,19 @@ public:
         check(svo_world_update(world_, i, &edited, tree_left, tree_right, twig_left, twig_right, realloc_ ? 1 : 0), "World::modify");
     }
 
+    // world.chunk[i].build / destroy / replace(cmin, cmax, ...) followed by world.modify(i, ...) (src/Main.cpp:340-367) in one
+    // call, on the device the world is uploaded to (svo_world_edit_box).
+    void build(int i, vec3 cmin, vec3 cmax, uint16_t material) { edit(i, SVO_EDIT_BUILD, cmin, cmax, material, "World::build"); }
+    void destroy(int i, vec3 cmin, vec3 cmax) { edit(i, SVO_EDIT_DESTROY, cmin, cmax, 0, "World::destroy"); }
+    void replace(int i, vec3 cmin, vec3 cmax, uint16_t material) { edit(i, SVO_EDIT_REPLACE, cmin, cmax, material, "World::replace"); }
+
+    // World::shift(offset): slide the grid by one chunk (src/World.cpp:334-378).
+    void shift(ivec3 offset)
+    {
+        const int o[3] = { offset.x, offset.y, offset.z };
+        check(svo_world_shift(world_, o), "World::shift");
+    }
+
     ivec3 index_float(vec3 p) const
     {
         const float pp[3] = { p.x, p.y, p.z };
@@ -158,6 +171,13 @@ public:
     int index(int x, int y, int z) const { return svo_world_index(world_, x, y, z); }
     svo_chunk_desc chunk(int i) const { svo_chunk_desc d; check(svo_world_chunk(world_, i, &d), "World::chunk"); return d; }
     svo_world *handle() const { return world_; }
+private:
+    void edit(int i, int op, vec3 cmin, vec3 cmax, uint16_t material, const char *where)
+    {
+        const float lo[3] = { cmin.x, cmin.y, cmin.z }, hi[3] = { cmax.x, cmax.y, cmax.z };
+        check(svo_world_edit_box(world_, i, op, lo, hi, material), where);
+    }
+public:
 
     int width = 0, height = 0, depth = 0, plane = 0, volume = 0, chunksize = 0;
 private:
