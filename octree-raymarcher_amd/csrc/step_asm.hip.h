@@ -253,12 +253,9 @@ __device__ __forceinline__ void march_steps_asm(
         "v_cvt_f32_i32 %[q2], %[q2]\n\t"
         "v_cvt_f32_i32 %[q3], %[q3]\n\t"
         "v_mul_f32 %[q4], %[rs], %[q4]\n\t"                    // cell edge
-        "v_mul_f32 %[q1], %[q1], %[rs]\n\t"
-        "v_mul_f32 %[q2], %[q2], %[rs]\n\t"
-        "v_mul_f32 %[q3], %[q3], %[rs]\n\t"
-        "v_add_f32 %[q1], %[lx], %[q1]\n\t"                    // cell lo
-        "v_add_f32 %[q2], %[ly], %[q2]\n\t"
-        "v_add_f32 %[q3], %[lz], %[q3]\n\t"
+        "v_fma_f32 %[q1], %[q1], %[rs], %[lx]\n\t"             // cell lo = l + k*res: product and sum are exact on exact geometry
+        "v_fma_f32 %[q2], %[q2], %[rs], %[ly]\n\t"             // (lattice values below 2^24 steps), so the fused form rounds
+        "v_fma_f32 %[q3], %[q3], %[rs], %[lz]\n\t"             // nowhere the reference's mul + add would
         "v_add_f32 %[q5], %[q1], %[q4]\n\t"                    // cell hi
         "v_add_f32 %[q6], %[q2], %[q4]\n\t"
         "v_add_f32 %[q7], %[q3], %[q4]\n\t"
