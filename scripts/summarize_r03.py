@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); tag = "r03"
 S = {}
 for name in ("prof_kt", "prof_kt_serial"):
-    f = glob.glob(os.path.join(G, name, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(G, name, "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)     # (gpurun merges into gpurun_out/: older runs' files stay)
     if not f: continue
     rows = list(csv.DictReader(open(f[0])))
     keep = [r for r in rows if "svo::" in r["Name"]]
