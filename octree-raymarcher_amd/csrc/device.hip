@@ -47,20 +47,33 @@ using namespace svo;
 namespace svo {
 
 // bit w of mask[b] = (brick b cell w != 0).  One thread per 16-byte eighth of a brick (8 cells -> one mask byte):
-// 16 B per lane, fully coalesced reads of the twig pool, byte stores into the little-endian uint64 masks.
-__global__ __launch_bounds__(256) void k_brick_masks(const uint16_t *twig, uint64_t *mask, uint64_t first, uint64_t count)
+// 16 B per lane, fully coalesced reads of the twig pool, byte stores into the little-endian uint64 masks.  The eight lanes of
+// a brick also agree on bmat[b]: the brick's material if all its non-empty cells hold the same one (what grow() produces), 0 for an
+// empty brick, 0xFFFF if it holds several (the hit block then reads the cell itself).
+__global__ __launch_bounds__(256) void k_brick_masks(const uint16_t *twig, uint64_t *mask, uint16_t *bmat, uint64_t first, uint64_t count)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;      // eighth-of-brick index
-    if (i >= count * 8) return;
-    const uint4 v = reinterpret_cast<const uint4 *>(twig + first * TWIG_WORDS)[i];
+    const bool live = i < count * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (live) v = reinterpret_cast<const uint4 *>(twig + first * TWIG_WORDS)[i];
     const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-    uint32_t bits = 0;
+    uint32_t bits = 0, lo = 0xFFFFu, hi = 0u;                       // smallest / largest non-zero material of this eighth
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        bits |= ((w[k] & 0xFFFFu) ? 1u : 0u) << (2 * k);
-        bits |= ((w[k] >> 16) ? 1u : 0u) << (2 * k + 1);
+        const uint32_t a = w[k] & 0xFFFFu, b = w[k] >> 16;
+        bits |= (a ? 1u : 0u) << (2 * k);
+        bits |= (b ? 1u : 0u) << (2 * k + 1);
+        if (a) { lo = a < lo ? a : lo; hi = a > hi ? a : hi; }
+        if (b) { lo = b < lo ? b : lo; hi = b > hi ? b : hi; }
     }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {                                   // the brick's eight lanes are neighbours (256 % 8 == 0)
+        const uint32_t lo2 = __shfl_xor(lo, d, 64), hi2 = __shfl_xor(hi, d, 64);
+        lo = lo2 < lo ? lo2 : lo; hi = hi2 > hi ? hi2 : hi;
+    }
+    if (!live) return;
     reinterpret_cast<uint8_t *>(mask + first)[i] = (uint8_t)bits;
+    if ((i & 7u) == 0u) bmat[first + (i >> 3)] = (uint16_t)(hi == 0u ? 0u : (lo == hi ? lo : 0xFFFFu));
 }
 
 // svo_tile_order: key = primary + shadow step maxima of the tile (saturating), value = the tile's index
@@ -78,7 +91,7 @@ static int launch_masks(svo_world &w, uint64_t first, uint64_t count, hipStream_
     if (!count) return SVO_OK;
     const uint64_t blocks = (count * 8 + 255) / 256;
     if (blocks > 0x7FFFFFFFull) { set_error("brick pool too large for one mask launch"); return SVO_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_brick_masks, dim3((unsigned)blocks), dim3(256), 0, s, w.d_twig, w.d_mask, first, count);
+    hipLaunchKernelGGL(k_brick_masks, dim3((unsigned)blocks), dim3(256), 0, s, w.d_twig, w.d_mask, w.d_bmat, first, count);
     HIP_TRY(hipGetLastError());
     return SVO_OK;
 }
@@ -88,13 +101,13 @@ int release_device(svo_world &w)
     if (w.device >= 0) {
         (void)hipSetDevice(w.device);
         (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
-        (void)hipFree(w.d_mask); (void)hipFree(w.d_work);
-        (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
+        (void)hipFree(w.d_mask); (void)hipFree(w.d_bmat); (void)hipFree(w.d_work);
+        (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
         for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
     }
     w.work_event.clear();
-    w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_work = nullptr;
-    w.d_wide = nullptr; w.d_wref = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
+    w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_bmat = nullptr; w.d_work = nullptr;
+    w.d_wide = nullptr; w.d_wbase = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
     w.d_sort = nullptr; w.sort_bytes = 0;
     w.device = -1;
     w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear(); w.wtable.clear(); w.wide_slot.clear();
@@ -122,10 +135,6 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, in
     const int64_t slots = in_flight >= 2 ? std::max<int64_t>(1, (int64_t)w->occupancy_blocks * 2 / in_flight) : w->occupancy_blocks;
     const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, slots);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
-#ifdef SVO_RAW_HITS
-    const int64_t records = A.n * (int64_t)(A.from_camera ? A.nframes : 1);
-    hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((records + 255) / 256)), dim3(256), 0, s, A);
-#endif
     return SVO_OK;
 }
 
@@ -196,6 +205,7 @@ int alloc_pools(svo_world &w, int device)
     if (hipMalloc((void **)&w.d_tree, w.tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_twig, w.twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_mask, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&w.d_bmat, w.twig_pool_cap * sizeof(uint16_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
         hipMalloc((void **)&w.d_wchunks, n * sizeof(DevWide)) != hipSuccess ||
         hipMalloc((void **)&w.d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
@@ -203,6 +213,7 @@ int alloc_pools(svo_world &w, int device)
     }
     if (hipMemset(w.d_tree, 0, w.tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(w.d_mask, 0, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(w.d_bmat, 0, w.twig_pool_cap * sizeof(uint16_t)) != hipSuccess ||
         hipMemset(w.d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); return SVO_ERR_HIP; }
     w.occupancy_blocks = 0;
     w.wide_ok = false;                                                  // until build_wide_all has run
@@ -232,8 +243,9 @@ int fetch_pools(svo_world &w, int chunk)
 }
 
 // The wide tree of chunk `chunk` (wide_tree.hip.h) from its node words in the tree pool, level by level, into
-// wide_dst / wref_dst (room for slot_cap wide nodes); *count = wide nodes written.
-static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *wide_dst, uint32_t *wref_dst, uint64_t slot_cap, uint64_t *count_out)
+// wide_dst / wbase_dst (room for slot_cap wide nodes); *count = wide nodes written.  The per-entry reference indices that link
+// one level to the next live in the builder's scratch.
+static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *wide_dst, uint32_t *wbase_dst, uint64_t slot_cap, uint64_t *count_out)
 {
     const ChunkPools &c = w.chunks[(size_t)chunk];
     const DevChunk &e = w.table[(size_t)chunk];
@@ -241,7 +253,7 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
     const uint32_t nw = levels == 0 ? 1u : (levels + 1u) / 2u;
     const int pad = (int)(2u * nw - levels);
     const uint64_t B = c.tree_count() / 8 + 1;                          // most BRANCH nodes (= wide nodes) a level can have
-    uint32_t *front = w.d_wscratch, *next = front + B, *flag = next + B, *rank = flag + 64 * B;
+    uint32_t *front = w.d_wscratch, *next = front + B, *flag = next + B, *rank = flag + 64 * B, *wref_dst = rank + 64 * B;
     const uint32_t *tree = w.d_tree + e.tree_off;
     HIP_TRY(hipMemsetAsync(front, 0, sizeof(uint32_t), s));             // the top wide node expands reference node 0
     uint32_t count = 1, first = 0;
@@ -252,7 +264,7 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
         if ((uint64_t)first + count > slot_cap) { set_error("wide tree: slot overflow"); rc = SVO_ERR_MALFORMED_TREE; break; }
         const uint32_t n = count * 64u;
         hipLaunchKernelGGL(k_wide_expand, dim3((n + 255) / 256), dim3(256), 0, s, tree, front, count, first,
-                           k == 0 ? pad : 0, 2u * k + 1u - (uint32_t)pad, wide_dst, wref_dst, flag);
+                           k == 0 ? pad : 0, 2u * k + 1u - (uint32_t)pad, wide_dst, wref_dst, wbase_dst, flag);
         if (hipGetLastError() != hipSuccess) { set_error("wide tree: launch failed"); rc = SVO_ERR_HIP; break; }
         if (k + 1 == nw) { first += count; count = 0; break; }         // grandchildren of the last wide level are never BRANCH
         size_t bytes = 0;
@@ -286,7 +298,7 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
 static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
 {
     const uint64_t B = largest_tree / 8 + 1;
-    const uint64_t need = 2 * B + 2 * 64 * B + 2 * 64 * B + 1024;
+    const uint64_t need = 2 * B + 2 * 64 * B + 2 * 64 * B + WIDE_BASE_WORDS * B + 1024;        // fronts, flags + ranks, entry references + a throw-away tree, its bases
     if (need <= w.wscratch_words) return SVO_OK;
     if (w.d_wscratch) { (void)hipDeviceSynchronize(); (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; }
     if (hipMalloc((void **)&w.d_wscratch, need * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipMalloc of the builder scratch failed"); return SVO_ERR_OUT_OF_MEMORY; }
@@ -305,7 +317,7 @@ static bool wide_fits(const svo_world &w, int chunk)
 // the build pass writes them in place.  The node words must already be in the tree pool.
 static void drop_wide(svo_world &w)
 {
-    (void)hipFree(w.d_wide); (void)hipFree(w.d_wref); w.d_wide = w.d_wref = nullptr;
+    (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); w.d_wide = w.d_wbase = nullptr;
     w.wide_ok = false;
     w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
 }
@@ -338,11 +350,11 @@ int build_wide_all(svo_world &w, void *stream)
     if (rc == SVO_OK && wide_fault_injected()) { set_error("wide tree: injected allocation failure"); rc = SVO_ERR_OUT_OF_MEMORY; }
     if (rc != SVO_OK) { drop_wide_scratch(w); return rc; }
     const uint64_t Bmax = largest / 8 + 1;
-    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
+    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 3 * 64 * Bmax, *tmp_wbase = tmp_wide + 64 * Bmax;
     uint64_t cur = 0, used = 0;
     for (size_t i = 0; i < n; ++i) {
         uint64_t count = 0;
-        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) { drop_wide_scratch(w); return rc; }
+        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wbase, Bmax, &count)) != SVO_OK) { drop_wide_scratch(w); return rc; }
         const DevChunk &e = w.table[i];
         DevWide &v = w.wtable[i];
         v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
@@ -354,13 +366,13 @@ int build_wide_all(svo_world &w, void *stream)
     const uint64_t cap = cur + cur / 16 + 64;
     if (cap * 64 >= (1ull << 30)) { drop_wide_scratch(w); return SVO_OK; }    // 32-bit byte offsets into the pool: literal kernel
     if (hipMalloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_wref, cap * 64 * sizeof(uint32_t)) != hipSuccess) {
+        hipMalloc((void **)&w.d_wbase, cap * WIDE_BASE_WORDS * sizeof(uint32_t)) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w);
         set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY;
     }
     for (size_t i = 0; i < n; ++i) {
         const DevWide &v = w.wtable[i];
-        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wref + (uint64_t)v.wide_off * 64, w.wide_slot[i], nullptr)) != SVO_OK) {
+        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wbase + (uint64_t)v.wide_off * WIDE_BASE_WORDS, w.wide_slot[i], nullptr)) != SVO_OK) {
             drop_wide(w); drop_wide_scratch(w); return rc;
         }
     }
@@ -389,9 +401,9 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
     if (rc == SVO_OK && wide_fault_injected()) { set_error("wide tree: injected allocation failure"); rc = SVO_ERR_OUT_OF_MEMORY; }
     if (rc != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
     const uint64_t Bmax = c.tree_count() / 8 + 1;
-    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 2 * 64 * Bmax, *tmp_wref = tmp_wide + 64 * Bmax;
+    uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 3 * 64 * Bmax, *tmp_wbase = tmp_wide + 64 * Bmax;
     uint64_t count = 0;
-    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wref, Bmax, &count)) != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
+    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wbase, Bmax, &count)) != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
     DevWide &v = w.wtable[(size_t)chunk];
     const DevChunk &e = w.table[(size_t)chunk];
     if (count > w.wide_slot[(size_t)chunk]) {
@@ -404,7 +416,7 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
     v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
     v.levels = e.levels; v.twig_off = e.twig_off;
     if (hipMemcpyAsync(w.d_wide + (uint64_t)v.wide_off * 64, tmp_wide, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(w.d_wref + (uint64_t)v.wide_off * 64, tmp_wref, count * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(w.d_wbase + (uint64_t)v.wide_off * WIDE_BASE_WORDS, tmp_wbase, count * WIDE_BASE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(w.d_wchunks + chunk, &v, sizeof(DevWide), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w); set_error("wide tree: copy of the rebuilt chunk failed"); return SVO_ERR_HIP;
@@ -629,7 +641,7 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
         A.cbase[a] = (dims[a] + (w->chunkcoordmin[a] % dims[a])) % dims[a];
     }
     A.chunks = w->d_chunks; A.tree = w->d_tree; A.twig = w->d_twig; A.mask = w->d_mask;
-    A.wchunks = w->d_wchunks; A.wide = w->d_wide; A.wref = w->d_wref;
+    A.wchunks = w->d_wchunks; A.wide = w->d_wide; A.wbase = w->d_wbase; A.bmat = w->d_bmat;
     A.eps = (prm && prm->eps != 0.0f) ? prm->eps : 1.0f / 8192.0f;
     A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
     A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;

@@ -53,11 +53,6 @@
 
 namespace svo {
 
-#ifdef SVO_RAW_HITS
-constexpr uint32_t SVO_RAW_IF = SVO_RAW_FLAG;
-#else
-constexpr uint32_t SVO_RAW_IF = 0u;
-#endif
 constexpr int CW_ESCAPE_PENDING = (int)0x80000000;    // bit of the lane's chunk-step counter: tw still lacks the escape out of the chunk just left
 enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     // (step_asm.hip.h: marching = mode > 2)
 
@@ -66,9 +61,6 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 #endif
 #ifndef SVO_VOTE_HIT
 #define SVO_VOTE_HIT 16          // primary hits waiting for their G-buffer record
-#endif
-#ifndef SVO_VOTE_HIT_RAW
-#define SVO_VOTE_HIT_RAW 4
 #endif
 #ifndef SVO_VOTE_BUSY
 #define SVO_VOTE_BUSY 24         // fewer marching lanes than this: serve the waiting ones regardless
@@ -464,7 +456,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const bool run_hit = n_hit > 0 && (n_hit >= SVO_VOTE_HIT || n_busy < SVO_VOTE_BUSY);
 
         if (SVO_UNLIKELY(mode != M_DONE && mode != M_HIT && ++guard > STEP_GUARD)) {     // runaway ray: give up, flag it
-            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | SVO_RAW_IF | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
+            if (outk < 0) store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_ERR_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
             else store_miss(A.out, outk, SVO_ERR_FLAG);
             mode = M_DONE;
         }
@@ -821,49 +813,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             }
         }
 
-#ifdef SVO_RAW_HITS
-        // ---- hits (experiment, see DESIGN.md "measured and not kept").  A primary hit writes a RAW record - t, the hit voxel's
-        //      box, the address of its wide-tree entry, the brick cell - and becomes its own shadow ray at once; material,
-        //      reference node index and normal are filled in by k_resolve_hits behind this kernel.
-        if (mode == M_HIT && outk < 0) {
-            store_flags(A.out, outk & 0x7FFFFFFF, SVO_HIT_FLAG | SVO_SHADOW_TRACED | SVO_SHADOWED | SVO_RAW_FLAG | (A.normal_mode == SVO_NORMAL_FACE ? (uint32_t)SVO_FACE_NORMAL : 0u));
-            mode = M_DONE;
-        }
-        const int n_hit_now = __popcll(__ballot(mode == M_HIT));
-        if (n_hit_now > 0 && (n_hit_now >= SVO_VOTE_HIT_RAW || n_busy < SVO_VOTE_BUSY) && mode == M_HIT) {
-#ifdef SVO_STACK_TIMING
-            n_hit_runs += 1;
-#endif
-            const int nw = levels ? (levels + 1) >> 1 : 1;
-            const uint32_t at = wide_b + ((((valid > 0 ? stk[valid][lane] : 0u) << 6) + wide_slot(pux, puy, puz, 2 * (nw - 1 - valid))) << 2);
-            const uint32_t hitc = (uint32_t)cnt;
-            V3 vlo;
-            float vsize;
-            if (hitc == SVO_CELL_NONE) {
-                const int low = (1 << (levels - plev)) - 1;
-                vlo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
-                vsize = res * (float)(low + 1);
-            } else {
-                vlo = mk(Blo.x + (float)(hitc & 3u) * res, Blo.y + (float)((hitc >> 2) & 3u) * res, Blo.z + (float)(hitc >> 4) * res);
-                vsize = res;
-            }
-            const bool face = A.normal_mode == SVO_NORMAL_FACE;
-            const uint32_t flags = SVO_HIT_FLAG | SVO_RAW_FLAG | (A.shadow ? SVO_SHADOW_TRACED : 0u) | (face ? (uint32_t)SVO_FACE_NORMAL : 0u);
-            store_raw_hit(A.out, outk, tw, vlo, vsize, flags, (uint32_t)ci, at, hitc);
-            mode = M_DONE;
-            if (A.shadow) {
-                alpha = alpha + beta * (tw - eps); beta = sdir; g = sg;
-                outk |= (int)0x80000000;
-                tw = 0.0f; cw = 0; guard = 0; creepn = 0;
-                bool hit = true;
-                if (!inside(alpha, wlo, whi)) tw = enter(alpha, beta, wlo, whi, hit) + eps;
-                mode = hit ? M_WORLD : M_DONE;
-                rays_marched++;
-            }
-        }
-    }
-
-#else
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
         if (mode == M_HIT && outk < 0) {
@@ -876,7 +825,17 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             const int nw = levels ? (levels + 1) >> 1 : 1;
             const uint32_t at = wide_b + ((((valid > 0 ? stk[valid][lane] : 0u) << 6) + wide_slot(pux, puy, puz, 2 * (nw - 1 - valid))) << 2);
             const uint32_t word = ld_node(A.wide, at);              // the terminal entry again (material / brick index) ...
-            const uint32_t node = ld_node(A.wref, at);              // ... and the reference node it stands for (svo_hit.node)
+            // ... and the reference node it stands for (svo_hit.node): the entry's wide node keeps the index of the child block it
+            // expands and of its eight grandchild blocks (wide_tree.hip.h: wbase); level 0 is the chunk's root, node 0
+            uint32_t node = 0u;
+            if (plev != 0) {
+                const uint32_t slot = (at >> 2) & 63u;
+                const uint32_t ci = ((slot >> 1) & 1u) | ((slot >> 2) & 2u) | ((slot >> 3) & 4u);
+                const uint32_t gi = (slot & 1u) | ((slot >> 1) & 2u) | ((slot >> 2) & 4u);
+                const uint32_t *wb = A.wbase + (size_t)(at >> 8) * WIDE_BASE_WORDS;
+                const int level_child = 2 * valid + 1 - (2 * nw - levels);
+                node = plev == level_child ? wb[0] + ci : wb[1 + ci] + gi;
+            }
             const uint32_t hitc = (uint32_t)cnt;                    // which brick cell (or SVO_CELL_NONE: a LEAF)
             V3 vlo;
             float vsize;
@@ -889,7 +848,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             } else {                                                // brick cell: frame = brick (Blo = node box, res = voxel)
                 vlo = mk(Blo.x + (float)(hitc & 3u) * res, Blo.y + (float)((hitc >> 2) & 3u) * res, Blo.z + (float)(hitc >> 4) * res);
                 vsize = res;
-                material = A.twig[((unsigned long long)twig_off + (word & WIDE_PAYLOAD)) * TWIG_WORDS + hitc];
+                // most bricks hold one material (grow() fills a brick with its node's): it is kept per brick next to the masks, 64
+                // bricks to a cache line; only a brick of several materials (0xFFFF) is read itself, 128 B for one cell
+                const unsigned long long brick = (unsigned long long)twig_off + (word & WIDE_PAYLOAD);
+                material = A.bmat[brick];
+                if (material == 0xFFFFu) material = A.twig[brick * TWIG_WORDS + hitc];
             }
             const V3 point = alpha + beta * (tw - eps);
             const bool face = A.normal_mode == SVO_NORMAL_FACE;
@@ -910,7 +873,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
     }
 
-#endif
     unsigned total = rays_marched;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
     if (lane == 0 && total) atomicAdd(&A.work[1], (unsigned long long)total);
@@ -928,44 +890,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 4] = h2;
     }
 #endif
-}
-
-// (experiment, -DSVO_RAW_HITS) second half of a stack-kernel launch: every record k_trace_stack left RAW gets its material,
-// reference node index and normal.  The ray is generated again by the same code that generated it for the march.
-__global__ __launch_bounds__(256) void k_resolve_hits(TraceArgs A)
-{
-    const int64_t total = A.n * (int64_t)(A.from_camera ? A.nframes : 1);
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= total) return;
-    uint4 *rec = reinterpret_cast<uint4 *>(A.out) + 2 * k;
-    const uint4 b = rec[1];
-    const uint32_t flags = b.x >> 16;
-    if (!(flags & SVO_RAW_FLAG)) return;
-    const uint4 a = rec[0];
-    V3 o, d;
-    if (A.from_camera) {
-        const int frame = (int)(k / A.n);
-        const int64_t r = k - (int64_t)frame * A.n;
-        const int ly = (int)(r / A.w), lx = (int)(r - (int64_t)ly * A.w);
-        int px, py;
-        local_to_pixel(A, lx, ly, px, py);
-        camera_ray(A.cams[frame], A.imgw, A.imgh, px, py, o, d);
-    } else {
-        o = ld3(A.origins + 3 * k);
-        d = ld3(A.dirs + 3 * k);
-    }
-    const float tw = __uint_as_float(a.x);
-    const V3 vlo = mk(__uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-    const float vsize = __uint_as_float(b.w);
-    const uint32_t hitc = b.x & 0xFFFFu;
-    const uint32_t word = ld_node(A.wide, b.z), node = ld_node(A.wref, b.z);
-    uint32_t material;
-    if (hitc == SVO_CELL_NONE) material = word & 0xFFFFu;
-    else material = A.twig[(A.wchunks[b.y].twig_off + (unsigned long long)(word & WIDE_PAYLOAD)) * TWIG_WORDS + hitc];
-    const V3 point = o + d * (tw - A.eps);
-    const bool face = A.normal_mode == SVO_NORMAL_FACE;
-    const V3 n = face ? face_normal(point, vlo, vlo + vsize, d) : cube_normal_pow2(point, vlo, vsize, A.eps);
-    store_hit(A.out, k, tw, n, material, flags & ~SVO_RAW_FLAG, b.y, node, hitc);
 }
 
 } // namespace svo

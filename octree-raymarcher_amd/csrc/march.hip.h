@@ -130,19 +130,6 @@ __device__ __forceinline__ void store_hit(void *out, int64_t k, float t, V3 n, u
     rec[0] = a;
     rec[1] = b;
 }
-// (experiment, -DSVO_RAW_HITS) internal flag of a record the stack kernel has written raw; cleared by k_resolve_hits
-constexpr uint32_t SVO_RAW_FLAG = 1u << 14;
-//   [t | voxel box lo.x lo.y lo.z] [cell (low 16) flags (high 16) | chunk | byte offset of the wide-tree entry | voxel edge]
-__device__ __forceinline__ void store_raw_hit(void *out, int64_t k, float t, V3 vlo, float vsize, uint32_t flags,
-                                              uint32_t chunk, uint32_t wide_at, uint32_t cell)
-{
-    uint4 a, b;
-    a.x = __float_as_uint(t); a.y = __float_as_uint(vlo.x); a.z = __float_as_uint(vlo.y); a.w = __float_as_uint(vlo.z);
-    b.x = (cell & 0xFFFFu) | (flags << 16); b.y = chunk; b.z = wide_at; b.w = __float_as_uint(vsize);
-    uint4 *rec = reinterpret_cast<uint4 *>(out) + 2 * k;
-    rec[0] = a;
-    rec[1] = b;
-}
 __device__ __forceinline__ void store_miss(void *out, int64_t k, uint32_t flags)
 {
     uint4 z; z.x = z.y = z.z = z.w = 0u;

@@ -54,6 +54,7 @@ constexpr int TILE_REGIONS = 8;
 #endif
 constexpr int TILE_W = SVO_TILE_W, TILE_H = 64 / TILE_W;
 static_assert(TILE_W * TILE_H == 64 && (TILE_W & (TILE_W - 1)) == 0, "a tile is one wave of rays");
+constexpr uint32_t WIDE_BASE_WORDS = 9;  // per wide node (wide_tree.hip.h): reference index of the child block and of the 8 grandchild blocks
 constexpr int WORK_CURSOR0 = 2;
 constexpr int WORK_SLOT_WORDS = 16;     // 128 B: slots do not share a cache line
 
@@ -70,7 +71,8 @@ struct TraceArgs {
     const DevChunk *chunks;
     const DevWide  *wchunks;    // stack kernel: chunk table over the wide pool
     const uint32_t *wide;       // wide pool: 64 entries per wide node (wide_tree.hip.h)
-    const uint32_t *wref;       // reference node index of every wide entry (for svo_hit.node)
+    const uint32_t *wbase;      // per wide node: reference index of the child block and of the 8 grandchild blocks it expands (for svo_hit.node)
+    const uint16_t *bmat;       // per brick: its one material, 0 if empty, 0xFFFF if it holds several
     const uint32_t *tree;
     const uint16_t *twig;
     const uint64_t *mask;

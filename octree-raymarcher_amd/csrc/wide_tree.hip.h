@@ -8,8 +8,10 @@
 //                                                 level of the reference node (a child of the BRANCH, level L+1, fills
 //                                                 the 8 positions it covers; a grandchild, level L+2, fills one), or
 //     branch    [2 | 0 | wide node index]         the grandchild is a BRANCH itself: descend into its wide node.
-// A parallel array (wref) keeps the reference node index of every entry for the hit record (svo_hit.node); nothing else of
-// tree[] is needed by the stack kernel.  The march is unchanged - the same leaf node, hence the same box and the same
+// For the hit record (svo_hit.node) every wide node keeps WIDE_BASE_WORDS = 9 reference indices (wbase): the block of the 8
+// children it expands and the blocks of their children - entry (child ci, grandchild gi) stands for node wbase[0] + ci if it is a
+// child-level terminal, wbase[1 + ci] + gi otherwise; nothing else of tree[] is needed by the stack kernel.  (The per-entry
+// reference indices the builder links the levels with are scratch.)  The march is unchanged - the same leaf node, hence the same box and the same
 // floats, is found for every position - in half the dependent loads and half the descent-loop rounds.
 //
 // Wide levels are counted from the top: wide level k covers the cell-coordinate bits [2(nw-1-k)+1 : 2(nw-1-k)],
@@ -40,7 +42,7 @@ __device__ __forceinline__ uint32_t wide_terminal(uint32_t word, uint32_t level)
 // (ignored for the top level when pad > 0).  Writes the 64 entries and reference indices of every wide node; an entry
 // whose grandchild is a BRANCH is left as (BRANCH << 30) with flag = 1 and ref = that grandchild: k_wide_link numbers it.
 __global__ __launch_bounds__(256) void k_wide_expand(const uint32_t *tree, const uint32_t *front, uint32_t count, uint32_t first_wide,
-                                                     int top_pad, uint32_t level_child, uint32_t *wide, uint32_t *wref, uint32_t *flag)
+                                                     int top_pad, uint32_t level_child, uint32_t *wide, uint32_t *wref, uint32_t *wbase, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count * 64u) return;
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256) void k_wide_expand(const uint32_t *tree, const
     const uint32_t ci = (sx >> 1) | ((sy >> 1) << 1) | ((sz >> 1) << 2);        // Octree::branch of the child, src/Octree.cpp:55-58
     const uint32_t gi = (sx & 1u) | ((sy & 1u) << 1) | ((sz & 1u) << 2);        // ... and of the grandchild
     uint32_t entry = 0u, ref = 0u, fl = 0u;                                     // default: EMPTY at level 0 (unreachable positions)
+    uint32_t base0 = 0u, base1 = 0u;                                            // block of the children / of child ci's children
     if (top_pad == 2) {                         // levels == 0: the chunk root is a terminal at the grandchild position 0
         if (slot == 0u) { entry = wide_terminal(tree[0], 0u); ref = 0u; }
     } else {
@@ -61,13 +64,14 @@ __global__ __launch_bounds__(256) void k_wide_expand(const uint32_t *tree, const
             const uint32_t r = front[wn];
             const uint32_t wr = tree[r];
             if (node_type(wr) != BRANCH) { entry = wide_terminal(wr, 0u); ref = r; reachable = false; }    // a chunk that is one terminal node
-            else child = node_offset(wr) + ci;
+            else { base0 = node_offset(wr); child = base0 + ci; }
         }
         if (reachable) {
             wc = tree[child];
             if (node_type(wc) != BRANCH) { entry = wide_terminal(wc, level_child); ref = child; }
             else {
-                const uint32_t g = node_offset(wc) + gi;
+                base1 = node_offset(wc);
+                const uint32_t g = base1 + gi;
                 const uint32_t wg = tree[g];
                 ref = g;
                 if (node_type(wg) != BRANCH) entry = wide_terminal(wg, level_child + 1u);
@@ -77,6 +81,9 @@ __global__ __launch_bounds__(256) void k_wide_expand(const uint32_t *tree, const
     }
     const uint64_t o = (uint64_t)(first_wide + wn) * 64u + slot;
     wide[o] = entry; wref[o] = ref; flag[i] = fl;
+    uint32_t *wb = wbase + (uint64_t)(first_wide + wn) * WIDE_BASE_WORDS;
+    if (slot == 0u) wb[0] = base0;
+    if (gi == 0u) wb[1 + ci] = base1;
 }
 
 // rank = exclusive scan of flag: the flagged entries become BRANCH -> wide node (next_first + rank), and their reference

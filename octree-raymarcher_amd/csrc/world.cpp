@@ -249,10 +249,10 @@ int svo_world_info_get(const svo_world *w, svo_world_info *o)
     for (const ChunkPools &c : w->chunks) { o->total_trees += c.tree_count(); o->total_twigs += c.twig_count(); }
     o->tree_pool_bytes = w->tree_pool_cap * sizeof(uint32_t);
     o->twig_pool_bytes = w->twig_pool_cap * TWIG_WORDS * sizeof(uint16_t);
-    o->mask_pool_bytes = w->twig_pool_cap * sizeof(uint64_t);
+    o->mask_pool_bytes = w->twig_pool_cap * (sizeof(uint64_t) + sizeof(uint16_t));     // occupancy masks + one material per brick
     o->max_chunk_depth = w->max_levels + (int)TWIG_LEVELS;
     o->exact_geometry = w->exact_geometry ? 1 : 0;
-    o->wide_pool_bytes = w->wide_pool_cap * 64 * sizeof(uint32_t) * 2;
+    o->wide_pool_bytes = w->wide_pool_cap * (64 + 9) * sizeof(uint32_t);               // 64 entries + 9 reference block indices per wide node
     o->wide_nodes = w->wide_nodes_used;
     return SVO_OK;
 }

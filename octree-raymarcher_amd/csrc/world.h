@@ -24,7 +24,8 @@ struct svo_world {
     uint32_t *d_tree = nullptr;
     uint16_t *d_twig = nullptr;
     uint64_t *d_mask = nullptr;
-    uint32_t *d_wide = nullptr, *d_wref = nullptr;  // wide tree of every chunk (wide_tree.hip.h) and its reference node indices
+    uint16_t *d_bmat = nullptr;                   // per brick: its one material / 0 (empty) / 0xFFFF (several), written with the masks
+    uint32_t *d_wide = nullptr, *d_wbase = nullptr; // wide tree of every chunk (wide_tree.hip.h) and, per wide node, the reference blocks it expands
     svo::DevWide *d_wchunks = nullptr;
     std::vector<svo::DevWide> wtable;             // host mirror of d_wchunks
     std::vector<uint64_t> wide_slot;              // capacity of each chunk's wide slot (wide nodes)
