@@ -658,7 +658,7 @@ def run(args):
                     "issue_utilisation_this_run_at_2.4GHz": round(iss["instructions_per_frame"] * iss["cycles_per_instruction_weighted"] / simd_cycles, 4),
                     "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
-                    "note": "the kernel sits at the instruction-issue limit: 0.91 of the issue slots of a serialized 16-frame launch, its one drain included "
+                    "note": "the kernel sits at the instruction-issue limit: 0.93 of the issue slots of a serialized 16-frame launch, its one drain included "
                             "(0.79 for an 8-frame launch), 0.95 with launches in flight, where the drains overlap (DESIGN.md §5)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
