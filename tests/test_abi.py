@@ -119,6 +119,12 @@ def test_no_device_means_error_not_fallback(svo):
     with pytest.raises(svo.SvoError) as e:
         W.trace(cam, svo.trace_params(), (0, 0, 8, 8), 0)
     assert e.value.code == -5                                        # not uploaded: nothing was traced on the CPU
+    with pytest.raises(svo.SvoError) as e:
+        W.edit_box(0, svo.EDIT_BUILD, (0, 0, 0), (8, 8, 8), 5)
+    assert e.value.code == -5                                        # ... and nothing is edited on the host behind the caller's back
+    with pytest.raises(svo.SvoError) as e:
+        svo.World.generate(1, 1, 1, 128, 4, build_device=0)
+    assert e.value.code == -2                                        # the device builder does not fall back to the host generator
     W.destroy()
 
 
