@@ -84,7 +84,7 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 #define SVO_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #endif
 #ifndef SVO_STEP_EXTRA
-#define SVO_STEP_EXTRA 3
+#define SVO_STEP_EXTRA 4
 #endif
 // steps per statement while the inner repeat lasts (the drain of a launch: the wave is alone on its SIMD, every instruction of the
 // loop control around the statement costs it ~5 cycles)
