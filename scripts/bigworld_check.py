@@ -8,7 +8,8 @@ svo = importlib.import_module("octree-raymarcher_amd")
 import oracle_binding as ob
 from helpers import assert_gbuffer_equal
 gw, gd, depth = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), (int(sys.argv[2]) if len(sys.argv) > 2 else 8), 12
-t = time.time(); W = svo.World.generate(gw, 1, gd, 128, depth); tg = time.time() - t
+on_device = len(sys.argv) > 3 and sys.argv[3] == "device"          # the device builder (noise, mips, grow, water fill as kernels) instead of host threads
+t = time.time(); W = svo.World.generate(gw, 1, gd, 128, depth, build_device=0 if on_device else None); tg = time.time() - t
 info = W.info
 print(f"generated {gw}x1x{gd} depth {depth} in {tg:.1f} s: {info.total_trees/1e6:.0f} M nodes, {info.total_twigs/1e6:.0f} M bricks "
       f"({info.total_twigs*64/2**32:.2f} x 2^32 brick cells)", flush=True)
