@@ -63,8 +63,9 @@ BAND = 8                       # rows per band == tile height of the stack kerne
 # A launch ends with a tail (its longest rays, each wave alone on its SIMD); the frames of one launch, behind one set of cursors,
 # pay it once, and the next launch's bulk runs under it.  The N > 1 rows come from one-GPU emulation of a rank's share
 # (--emulate-share) and are unmeasured on real multi-GPU hardware.
-STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 4, 8: 4}       # launches in flight per rank when a frame is split N ways
-FRAMES_PER_LAUNCH = {1: 8, 2: 8, 4: 16, 8: 16}      # consecutive frames marched by one launch (and shipped by one gather)
+# (re-measured at the end of round 3 with scripts/sweep_share.sh: 1/4 share 8 x 16 -> 6 675 against 6 205 Mrays/s with 4 x 16, 1/8 share 6 283 against 6 139)
+STREAMS_FOR_SHARE = {1: 4, 2: 4, 4: 8, 8: 8}       # launches in flight per rank when a frame is split N ways
+FRAMES_PER_LAUNCH = {1: 8, 2: 16, 4: 16, 8: 16}     # consecutive frames marched by one launch (and shipped by one gather)
 # N = 1, per workload (launches in flight, frames per launch).  The depth-12 4x1x4 worlds: two launches of up to 16 frames give the
 # throughput of four of eight (6.9 Grays/s either way, 5.9 at 20 steps) and spread a launch's one drain over twice the frames
 # (serialized launch: 0.566 against 0.640 ms per frame).  C2's and C5's frames are short (0.2 - 0.3 ms): they want four launches in
