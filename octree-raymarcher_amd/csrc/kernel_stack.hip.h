@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
+    StepStats step_stats;
     unsigned n_wsteps = 0, n_lsteps = 0, n_hit_wait = 0, n_dead_wait = 0, n_wsteps_b = 0, n_lsteps_b = 0, n_world_wait = 0, n_twig_b = 0;   // step bodies executed, marching lanes summed over them; M_HIT / M_DONE lanes summed over them
 #endif
 
@@ -534,7 +535,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // (step_asm.hip.h) the steps of this pass in one statement: 1 + fixed_steps at first, single steps while the inner repeat lasts
         const int nsteps = pass == 0 ? 1 + fixed_steps : SVO_DRAIN_STEPS;
         march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                        beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps);
+                        beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps
+#ifdef SVO_STACK_TIMING
+                        , step_stats
+#endif
+                        );
         pass += nsteps - 1;
 #else
         if (mode == M_TREE || mode == M_TWIG) {
@@ -879,15 +884,17 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_STACK_TIMING
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
-        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x] = c;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
-        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 1] = e;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 1] = e;
         uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = n_dbg;
-        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 2] = f;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 2] = f;
         uint4 h; h.x = n_wsteps; h.y = n_lsteps; h.z = n_hit_wait; h.w = n_dead_wait;
-        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 3] = h;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 3] = h;
         uint4 h2; h2.x = n_wsteps_b; h2.y = n_lsteps_b; h2.z = n_world_wait; h2.w = n_twig_b;
-        reinterpret_cast<uint4 *>(A.counters)[5 * blockIdx.x + 4] = h2;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 4] = h2;
+        uint4 h3; h3.x = step_stats.steps; h3.y = step_stats.lanes; h3.z = step_stats.stalls; h3.w = step_stats.chased;
+        reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 5] = h3;
     }
 #endif
 }

@@ -35,10 +35,17 @@
 #ifndef SVO_DESCEND_SHIFT
 #define SVO_DESCEND_SHIFT 2      // a wide level is taken inside the step when more than 1 / 2^this of the wave's tree lanes stand at a BRANCH entry
 #endif
+#ifdef SVO_STACK_TIMING
+#define SVO_STAT(text) text
+#else
+#define SVO_STAT(text) ""
+#endif
 #define SVO_STR_(x) #x
 #define SVO_STR(x) SVO_STR_(x)
 
 namespace svo {
+
+struct StepStats { unsigned steps = 0, lanes = 0, stalls = 0, chased = 0; };    // (-DSVO_STACK_TIMING) wave-steps, marching lanes summed over them, lanes that sat a BRANCH out, lanes that took a level inside the step
 
 struct StepUniform {            // wave-uniform inputs (SGPRs)
     float csize, eps, eps2;
@@ -53,13 +60,21 @@ __device__ __forceinline__ void march_steps_asm(
     int &mode, V3 &O, V3 &Blo, float &bsize, float &res, float &t, int &cnt, float &tt_saved, float &t_miss, int &it_saved,
     float &tw, int &cw, int &pux, int &puy, int &puz, int &valid, int &plev, unsigned long long &bmask, int &creepn,
     const V3 beta, const V3 g, const V3 clo, const V3 alpha, const int levels, const int nw, const float res_tree,
-    const uint32_t wide_b, const uint32_t twig_off, const uint32_t lds_lane, const StepUniform U, const int nsteps)
+    const uint32_t wide_b, const uint32_t twig_off, const uint32_t lds_lane, const StepUniform U, const int nsteps
+#ifdef SVO_STACK_TIMING
+    , StepStats &stats
+#endif
+    )
 {
     float px, py, pz, q1, q2, q3, q4, q5, q6, q7, r1, r2, r3;     // (r1..r3 double as the lattice quotients, low as 1/res, q7 as the brick cell index)
     int ux, uy, uz, low;
     uint32_t w;
     unsigned long long sall, smar, stw, sstay, sadv, sent, q64;
     int sctr, na, nb;
+#ifdef SVO_STACK_TIMING
+    unsigned st_steps = (unsigned)__builtin_amdgcn_readfirstlane((int)stats.steps), st_lanes = (unsigned)__builtin_amdgcn_readfirstlane((int)stats.lanes);
+    unsigned st_stalls = (unsigned)__builtin_amdgcn_readfirstlane((int)stats.stalls), st_chased = (unsigned)__builtin_amdgcn_readfirstlane((int)stats.chased);
+#endif
     asm volatile(
         "s_mov_b64 %[sall], exec\n\t"
         "s_mov_b32 %[sctr], %[nst]\n\t"
@@ -67,6 +82,7 @@ __device__ __forceinline__ void march_steps_asm(
         "v_cmpx_lt_u32 vcc, 2, %[md]\n\t"                      // marching lanes: TREE (3) or TWIG (4)
         "s_mov_b64 %[smar], exec\n\t"
         "s_cbranch_execz 91f\n\t"                              // nobody: the remaining steps would do nothing either
+        SVO_STAT("s_bcnt1_i32_b64 %[na], exec\n\t" "s_add_u32 %[st_steps], %[st_steps], 1\n\t" "s_add_u32 %[st_lanes], %[st_lanes], %[na]\n\t")
         // ---- p = O + beta*t and its lattice coordinates in the level's box (src/Traverse.cpp:80,55-58)
         "v_cmp_eq_u32_e64 %[stw], 4, %[md]\n\t"
         "v_mul_f32 %[px], %[bx], %[t]\n\t"
@@ -210,6 +226,7 @@ __device__ __forceinline__ void march_steps_asm(
         "ds_write_b32 %[q2], %[q3]\n\t"
         "s_cmp_gt_u32 %[na], %[nb]\n\t"
         "s_cbranch_scc0 35f\n\t"
+        SVO_STAT("s_add_u32 %[st_chased], %[st_chased], %[na]\n\t")
         "v_sub_u32 %[q4], %[nw], %[val]\n\t"                   // many: the next wide level now
         "v_lshl_add_u32 %[q4], %[q4], 1, -2\n\t"
         "v_bfe_u32 %[q1], %[ux], %[q4], 2\n\t"
@@ -224,6 +241,7 @@ __device__ __forceinline__ void march_steps_asm(
         "s_waitcnt vmcnt(0)\n\t"
         "s_branch 3b\n\t"
         "35:\n\t"
+        SVO_STAT("s_add_u32 %[st_stalls], %[st_stalls], %[na]\n\t")
         "v_add_u32 %[cnt], 1, %[cnt]\n\t"                      // few: these lanes sit the step out
         "s_andn2_b64 %[smar], %[smar], exec\n\t"
         "4:\n\t"
@@ -361,11 +379,17 @@ __device__ __forceinline__ void march_steps_asm(
           [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3), [q4] "=&v"(q4), [q5] "=&v"(q5), [q6] "=&v"(q6), [q7] "=&v"(q7),
           [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [low] "=&v"(low), [w] "=&v"(w), [q64] "=&v"(q64),
           [sall] "=&s"(sall), [smar] "=&s"(smar), [stw] "=&s"(stw), [sstay] "=&s"(sstay), [sadv] "=&s"(sadv), [sent] "=&s"(sent), [sctr] "=&s"(sctr), [na] "=&s"(na), [nb] "=&s"(nb)
+#ifdef SVO_STACK_TIMING
+          , [st_steps] "+s"(st_steps), [st_lanes] "+s"(st_lanes), [st_stalls] "+s"(st_stalls), [st_chased] "+s"(st_chased)
+#endif
         : [bx] "v"(beta.x), [by] "v"(beta.y), [bz] "v"(beta.z), [gx] "v"(g.x), [gy] "v"(g.y), [gz] "v"(g.z),
           [clx] "v"(clo.x), [cly] "v"(clo.y), [clz] "v"(clo.z), [ax] "v"(alpha.x), [ay] "v"(alpha.y), [az] "v"(alpha.z),
           [lev] "v"(levels), [nw] "v"(nw), [rtr] "v"(res_tree), [wb] "v"(wide_b), [tof] "v"(twig_off), [lds] "v"(lds_lane),
           [csz] "s"(U.csize), [eps] "s"(U.eps), [eps2] "s"(U.eps2), [captw] "s"(U.cap_twig), [wide] "s"(U.wide), [maskp] "s"(U.mask), [nst] "s"(nsteps)
         : "vcc", "scc", "memory");
+#ifdef SVO_STACK_TIMING
+    stats.steps = st_steps; stats.lanes = st_lanes; stats.stalls = st_stalls; stats.chased = st_chased;
+#endif
 }
 
 } // namespace svo

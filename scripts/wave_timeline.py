@@ -22,13 +22,14 @@ if os.environ.get("SVO_PATH_CAMS"):                     # F consecutive cameras 
     cams = [path[(int(os.environ["SVO_PATH_CAMS"]) + i) % len(path)] for i in range(F)]
 out = svo.DeviceBuffer(F * 1920 * 1080 * 32)
 for rep in range(3):
-    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 20), np.uint32))
+    cnt = svo.DeviceBuffer.from_numpy(np.zeros((nblk, 24), np.uint32))
     prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, counters_dev=cnt.ptr)
     W.trace_frames(cams, prm, (0, 0, 1920, 1080), out.ptr)
     svo.lib.svo_stream_synchronize(None)
-    c8 = cnt.to_numpy(np.uint32, nblk * 20).reshape(nblk, 20); c = c8[:, :4]; e = c8[:, 4:8]; f = c8[:, 8:12]; h = c8[:, 12:20]
-e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; h = h[c[:, 2] > 0]; c = c[c[:, 2] > 0]
+    c8 = cnt.to_numpy(np.uint32, nblk * 24).reshape(nblk, 24); c = c8[:, :4]; e = c8[:, 4:8]; f = c8[:, 8:12]; h = c8[:, 12:20]; st = c8[:, 20:24]
+e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; h = h[c[:, 2] > 0]; st = st[c[:, 2] > 0]; c = c[c[:, 2] > 0]
 t0 = c[:, 0].min()
+stats = st.astype(np.int64).sum(axis=0)
 st = (c[:, 0] - t0).astype(np.int64) * 0.01      # us
 en = (c[:, 1] - t0).astype(np.int64) * 0.01
 print("waves that ran:", len(c), "kernel span %.1f us" % en.max())
@@ -58,3 +59,5 @@ b = max(1, hs[4])
 print("while tiles remain (bulk): %d step bodies (%.1f %% of all), per step body: marching %.2f (in a brick %.2f), waiting for the chunk step %.2f, for the hit vote %.2f, retired %.2f" % (
     hs[4], 100.0 * hs[4] / max(1, hs[0]), hs[5] / b, hs[7] / b, hs[6] / b, hs[2] / b, hs[3] / b))
 print("lane-steps total %d" % hs[1])
+print("asm steps %d (%.2f per statement): marching lanes per step %.2f, of them %.2f sit a BRANCH out (%.1f %%), %.2f take a level inside the step" % (
+    stats[0], stats[0] / max(1, hs[0]), stats[1] / max(1, stats[0]), stats[2] / max(1, stats[0]), 100.0 * stats[2] / max(1, stats[1]), stats[3] / max(1, stats[0])))
