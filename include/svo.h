@@ -232,7 +232,8 @@ int svo_world_create(const svo_chunk_desc *chunks, int n, int w, int h, int d, i
                      const int chunkcoordmin[3], svo_world **out);
 
 int  svo_world_info_get(const svo_world *, svo_world_info *out);
-/* Borrow the host copy of chunk i (valid until the world is destroyed or chunk i is updated). */
+/* Borrow the host copy of chunk i (valid until the world is destroyed or chunk i is replaced: svo_world_update,
+ * svo_world_edit_box, a svo_world_shift that slides it out).  A chunk built or edited on the device is fetched on the first request. */
 int  svo_world_chunk(const svo_world *, int i, svo_chunk_desc *out);
 void svo_world_destroy(svo_world *);
 
