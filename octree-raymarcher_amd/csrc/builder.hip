@@ -696,6 +696,27 @@ static int generate_world_resident_impl(svo_world &w, int device)
     return SVO_OK;
 }
 
+// What svo_world_shift and svo_world_edit_box keep between calls on an uploaded world (created by the first one, freed with the
+// device copy): the builders' working buffers - a few hundred MB for depth-12 chunks - so that an interactive caller's edits and
+// slides do not pay some forty hipMalloc / hipFree each.
+struct BuilderContext {
+    DevicePyramidBuilder pyr;
+    DeviceGrower grower;
+    DeviceFiller filler;
+    DevBuf<uint32_t> edit_tree;
+    DevBuf<uint16_t> edit_twig;
+};
+static BuilderContext &builder_context(svo_world &w)
+{
+    if (!w.builder_ctx) w.builder_ctx = new BuilderContext();
+    return *static_cast<BuilderContext *>(w.builder_ctx);
+}
+void free_builder_context(svo_world &w)
+{
+    delete static_cast<BuilderContext *>(w.builder_ctx);
+    w.builder_ctx = nullptr;
+}
+
 // World::shift (src/World.cpp:334-378) on an uploaded world: the plane of chunks entering the grid is generated on the device
 // the pools live on (g_pyramid + g_chunk as in generate_world_resident_impl) and takes the slots of the plane that leaves -
 // the toroidal index of a chunk coordinate does not depend on chunkcoordmin -, then chunkcoordmin moves.
@@ -710,9 +731,10 @@ static int shift_world_resident_impl(svo_world &w, int axis, int sign)
     lo[axis] = u; hi[axis] = u + 1;
     BUILD_TRY(hipSetDevice(w.device));
     hipStream_t s = nullptr;
-    DevicePyramidBuilder pyr;
-    DeviceGrower grower;
-    DeviceFiller filler;
+    BuilderContext &ctx = builder_context(w);
+    DevicePyramidBuilder &pyr = ctx.pyr;
+    DeviceGrower &grower = ctx.grower;
+    DeviceFiller &filler = ctx.filler;
     for (int cz = lo[2]; cz < hi[2]; ++cz)
         for (int cx = lo[0]; cx < hi[0]; ++cx) {
             int rc = pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift,
@@ -751,8 +773,9 @@ static int edit_box_resident_impl(svo_world &w, int chunk, int op, const float l
     const ChunkPools &c = w.chunks[(size_t)chunk];
     const DevChunk &e = w.table[(size_t)chunk];
     uint64_t trees = c.tree_count(), twigs = c.twig_count();
-    DevBuf<uint32_t> tree;
-    DevBuf<uint16_t> twig;
+    BuilderContext &ctx = builder_context(w);
+    DevBuf<uint32_t> &tree = ctx.edit_tree;
+    DevBuf<uint16_t> &twig = ctx.edit_twig;
     int rc;
     if ((rc = tree.reserve(trees + 1024, false, s)) != SVO_OK || (rc = twig.reserve((twigs + 16) * TWIG_WORDS, false, s)) != SVO_OK) return rc;
     BUILD_TRY(hipMemcpyAsync(tree.p, w.d_tree + e.tree_off, trees * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
@@ -761,7 +784,7 @@ static int edit_box_resident_impl(svo_world &w, int chunk, int op, const float l
     std::memcpy(meta.position, c.position, sizeof meta.position);
     meta.size = c.size; meta.depth = c.depth;
     meta.tree_capacity = c.tree_capacity; meta.twig_capacity = c.twig_capacity;
-    DeviceFiller filler;
+    DeviceFiller &filler = ctx.filler;
     if (op == SVO_EDIT_DESTROY || op == SVO_EDIT_REPLACE)
         if ((rc = filler.fill(meta, lo, hi, material, tree, trees, twig, twigs, s, EDIT_DESTROY)) != SVO_OK) return rc;
     if (op == SVO_EDIT_BUILD || op == SVO_EDIT_REPLACE)

@@ -100,6 +100,7 @@ int release_device(svo_world &w)
 {
     if (w.device >= 0) {
         (void)hipSetDevice(w.device);
+        free_builder_context(w);
         (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
         (void)hipFree(w.d_mask); (void)hipFree(w.d_bmat); (void)hipFree(w.d_work);
         (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
@@ -448,7 +449,10 @@ static int world_upload_impl(svo_world *w, int device, bool force = false)
     const std::vector<DevChunk> table = w->table;
     const std::vector<uint64_t> tslot = w->tree_slot, bslot = w->twig_slot;
     const uint64_t tl = w->tree_pool_len, bl = w->twig_pool_len, tc = w->tree_pool_cap, bc = w->twig_pool_cap;
+    void *ctx = w->device == device ? w->builder_ctx : nullptr;          // a re-pack on the same device keeps the builders' buffers: the caller may be one of them
+    if (ctx) w->builder_ctx = nullptr;
     release_device(*w);                                                 // (clears the plan too)
+    w->builder_ctx = ctx;
     w->table = table; w->tree_slot = tslot; w->twig_slot = bslot;
     w->tree_pool_len = tl; w->twig_pool_len = bl; w->tree_pool_cap = tc; w->twig_pool_cap = bc;
 

@@ -32,6 +32,7 @@ struct svo_world {
     uint64_t wide_pool_len = 0, wide_pool_cap = 0, wide_nodes_used = 0;
     uint32_t *d_wscratch = nullptr;               // builder scratch: fronts, flags, ranks
     uint64_t wscratch_words = 0;
+    void *builder_ctx = nullptr;                  // builder.hip: working buffers svo_world_shift / svo_world_edit_box keep between calls
     void *d_sort = nullptr;                       // svo_tile_order scratch
     size_t sort_bytes = 0;
     bool wide_ok = false;                         // every chunk's bricks fit the 26-bit payload
@@ -64,6 +65,7 @@ int  install_resident_chunk(svo_world &w, int chunk, const ChunkPools &meta, con
 int  rebuild_wide_chunk(svo_world &w, int chunk, void *stream);
 // builder.hip: World::init on the device, pools left in HBM (the world is uploaded to `device` when this returns)
 int  generate_world_resident(svo_world &w, int device);
+void free_builder_context(svo_world &w);
 // builder.hip: Ocroot::build / destroy / replace + World::modify on an uploaded world
 int  edit_box_resident(svo_world &w, int chunk, int op, const float lo[3], const float hi[3], uint32_t material);
 // builder.hip: World::shift's entering plane generated on the device the world is uploaded to
