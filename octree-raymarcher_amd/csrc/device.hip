@@ -322,8 +322,11 @@ static void drop_wide(svo_world &w)
     w.wide_ok = false;
     w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
 }
-static void drop_wide_scratch(svo_world &w)
+static void drop_wide_scratch(svo_world &w, bool failed = true)
 {
+    // after a successful rebuild an interactive caller (one that has edited or slid the world: builder_ctx) keeps the scratch for
+    // the next one; everybody else gets the ~1 GB back
+    if (!failed && w.builder_ctx) return;
     if (w.d_wscratch) { (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; }
     w.wscratch_words = 0;
 }
@@ -385,7 +388,7 @@ int build_wide_all(svo_world &w, void *stream)
     // the builder's scratch (fronts, flags, ranks and a throw-away tree of the largest chunk: ~1 GB at C3) is only needed
     // here and by svo_world_update, which re-reserves what the edited chunk needs
     (void)hipStreamSynchronize(s);
-    drop_wide_scratch(w);
+    drop_wide_scratch(w, false);
     return SVO_OK;
 }
 
@@ -422,7 +425,7 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
         hipStreamSynchronize(s) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w); set_error("wide tree: copy of the rebuilt chunk failed"); return SVO_ERR_HIP;
     }
-    drop_wide_scratch(w);
+    drop_wide_scratch(w, false);
     return SVO_OK;
 }
 
