@@ -60,7 +60,7 @@ def test_edit_box_equals_the_oracles_edits(svo, oracle):
     D.destroy()
 
 
-@pytest.mark.parametrize("depth,seed", [(6, 1), (9, 2)])
+@pytest.mark.parametrize("depth,seed", [(6, 1), (9, 2), (11, 3)])
 def test_random_edit_sequences(svo, oracle, depth, seed):
     """Forty random edits of all three kinds - boxes from a voxel to half a chunk, on and off the lattice - on one chunk: pools
     equal the oracle's after every tenth edit and at the end (slots are outgrown and the world re-packed on the way)."""
