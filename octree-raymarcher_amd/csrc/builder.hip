@@ -312,6 +312,7 @@ struct DevicePyramidBuilder {
 // A node the edit creates has no slot until sweep C: until its parent numbers it, its list entry carries FILL_VIRTUAL and what
 // the reference would read there (EMPTY, or LEAF + material).
 enum FillAction : uint32_t { FILL_NONE = 0, FILL_SET, FILL_NEW_BRICK, FILL_SPLIT, FILL_BRICK, FILL_DESCEND };
+static_assert(FILL_DESCEND < (1u << FILL_ACTION_BITS), "every FillAction fits fill_pack's action field");
 enum EditOp : uint32_t { EDIT_BUILD = 0, EDIT_DESTROY = 1 };
 constexpr uint32_t FILL_VIRTUAL = 0x80000000u, FILL_VIRTUAL_LEAF = 0x00010000u;
 
@@ -323,7 +324,7 @@ struct FillArgs {
     uint32_t op;                // EDIT_BUILD / EDIT_DESTROY
 };
 
-// act[i] = action | kids << 8 (kids = index of the node's child block in the next level's list)
+// act[i] = fill_pack(action, kids) (kids = index of the node's child block in the next level's list; svo_format.h)
 __global__ __launch_bounds__(256) void k_fill_classify(const Cell *cells, uint32_t n, FillArgs F, const uint32_t *tree,
                                                        uint32_t *act, Cell *next, uint32_t *counters /* [0] child blocks, [1] brick edits */)
 {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void k_fill_classify(const Cell *cells, uint32
         }
     }
     if (a == FILL_NEW_BRICK || a == FILL_BRICK) atomicAdd(&counters[1], 1u);
-    act[i] = a | (kids << 8);
+    act[i] = fill_pack(a, kids);
 }
 
 // cnt[i] = {splits, new bricks} in the subtree of node i, itself included
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fill_count(const uint32_t *act, uint32_
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t a = act[i] & 255u, kids = act[i] >> 8;
+    const uint32_t a = fill_action(act[i]), kids = fill_kids(act[i]);
     uint2 v = make_uint2(a == FILL_SPLIT ? 1u : 0u, a == FILL_NEW_BRICK ? 1u : 0u);
     if (a == FILL_SPLIT || a == FILL_DESCEND) {
 #pragma unroll
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fill_number(Cell *cells, uint32_t n, Fi
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t a = act[i] & 255u, kids = act[i] >> 8;
+    const uint32_t a = fill_action(act[i]), kids = fill_kids(act[i]);
     if (a == FILL_NONE) return;
     const Cell e = cells[i];                // (its slot is a real one by now: the parent's turn came a launch earlier)
     const uint2 base = cnt[i];
@@ -500,7 +501,8 @@ struct DeviceFiller {
             BUILD_TRY(hipMemcpyAsync(h_counters, counters.p + 2 * level, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             BUILD_TRY(hipStreamSynchronize(s));
             brick_edits += h_counters[1];
-            if ((uint64_t)h_counters[0] * 8 >= (1ull << 31)) { set_error("device builder: the fill's frontier exceeds 2^31 nodes"); return SVO_ERR_UNSUPPORTED; }
+            // (also what fill_pack can hold: child-block indices stay below FILL_KIDS_LIMIT = 2^28)
+            if ((uint64_t)h_counters[0] >= FILL_KIDS_LIMIT) { set_error("device builder: the fill's frontier exceeds 2^31 nodes"); return SVO_ERR_UNSUPPORTED; }
             N.n = h_counters[0] * 8u;
             edge = edge * 0.5f;
             if (N.n == 0) break;

@@ -26,6 +26,18 @@ constexpr uint32_t node_make(uint32_t type, uint32_t offset) { return (type << 3
 constexpr uint32_t node_type(uint32_t w) { return w >> 30; }
 constexpr uint32_t node_offset(uint32_t w) { return w & OFFSET_MASK; }
 
+// The device fill (builder.hip: Ocroot::build / destroy as three level-synchronous sweeps) keeps one word per visited node:
+// its action (3 bits, FillAction) and the index of its child block in the next level's list.  A level holds fewer than
+// FILL_KIDS_LIMIT child blocks (the fill refuses larger frontiers: 8 * 2^28 list entries is its 2^31 limit), so the index has
+// 29 bits to itself - until round 4 it shared the word with an 8-bit action and lost its top bits from 2^24 blocks on.
+constexpr uint32_t FILL_ACTION_BITS = 3;
+constexpr uint64_t FILL_KIDS_LIMIT = 1ull << 28;
+constexpr uint32_t fill_pack(uint32_t action, uint32_t kids) { return action | (kids << FILL_ACTION_BITS); }
+constexpr uint32_t fill_action(uint32_t w) { return w & ((1u << FILL_ACTION_BITS) - 1u); }
+constexpr uint32_t fill_kids(uint32_t w) { return w >> FILL_ACTION_BITS; }
+static_assert(fill_kids(fill_pack(5u, (uint32_t)FILL_KIDS_LIMIT - 1u)) == FILL_KIDS_LIMIT - 1u && fill_action(fill_pack(5u, (uint32_t)FILL_KIDS_LIMIT - 1u)) == 5u,
+              "the largest child-block index the fill admits survives the packing");
+
 struct DevChunk {               // 32 bytes
     float    bmin[3];
     uint32_t levels;            // depth - TWIG_LEVELS: deepest level a node can sit at

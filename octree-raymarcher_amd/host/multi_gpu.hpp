@@ -19,7 +19,8 @@
 // march of the next (frames in flight, as bench.py does it).
 //
 // The N > 1 path is UNVERIFIED on hardware: the GPU boxes this was developed on have one device; with one device the
-// exchange degenerates to the strided copies (tests/test_cpp_adaptor.py runs that).  multi_gpu_example checks the
+// exchange degenerates to the strided copies (tests/test_cpp_adaptor.py runs that).  Its index arithmetic (band_layout.hpp)
+// is checked on a CPU for N = 2, 4, 8 with memcpy standing in for the copies (tests/test_host_units.py).  multi_gpu_example checks the
 // gathered frames against single-device frames, record for record, on however many devices it is given.
 //
 // The reference has no counterpart (one GL context, one GPU: src/Main.cpp); this is the build's extension of
@@ -35,14 +36,13 @@
 #include <thread>
 #include <vector>
 
+#include "band_layout.hpp"
 #include "svo_world.hpp"
 
 namespace svo {
 
 inline void hip_check(hipError_t e, const char *where) { if (e != hipSuccess) throw std::runtime_error(std::string(where) + ": " + hipGetErrorString(e)); }
 inline void nccl_check(ncclResult_t r, const char *where) { if (r != ncclSuccess) throw std::runtime_error(std::string(where) + ": " + ncclGetErrorString(r)); }
-
-constexpr int BAND = 8;                                  // rows per band == tile height of the stack kernel
 
 class MultiGpuWorld {
 public:
@@ -126,7 +126,8 @@ public:
         p.launches_in_flight = SLOTS;                       // calls alternate between SLOTS slots
         if (light_dir) std::memcpy(p.light_dir, light_dir, sizeof p.light_dir);
         std::vector<svo_camera> plain(cams.begin(), cams.end());
-        const size_t share = (size_t)F * (size_t)S.nb * BAND * (size_t)S.width;            // records of one rank, all frames
+        const BandLayout L{ n_, S.width, S.height, F };       // (band_layout.hpp: the arithmetic, checked on a CPU for N = 2, 4, 8)
+        const size_t share = L.share_records();             // records of one rank, all frames
         for (int r = 0; r < n_; ++r) {                      // every device: its bands of every frame, then the 8-byte form
             hip_check(hipSetDevice(r), "hipSetDevice");
             check(svo_trace_rows_frames(worlds_[(size_t)r]->handle(), plain.data(), F, &p, r, n_, S.nb, BAND, S.bands[(size_t)r], S.streams[(size_t)r]), "svo_trace_rows_frames");
@@ -142,12 +143,11 @@ public:
         }
         // band k of rank r of frame f = rows (k*N + r)*8 .. of that frame: one strided copy per (frame, rank) on device 0
         hip_check(hipSetDevice(0), "hipSetDevice");
-        const size_t band_bytes = (size_t)BAND * (size_t)S.width * 8;
         for (int f = 0; f < F; ++f)
             for (int r = 0; r < n_; ++r) {
-                const uint64_t *src = (r == 0 ? S.packed[0] : S.staging[(size_t)r]) + (size_t)f * (size_t)S.nb * BAND * (size_t)S.width;
-                uint64_t *dst = S.frames + (size_t)f * S.frame_stride + (size_t)r * BAND * (size_t)S.width;
-                hip_check(hipMemcpy2DAsync(dst, band_bytes * (size_t)n_, src, band_bytes, band_bytes, (size_t)S.nb, hipMemcpyDeviceToDevice, S.streams[0]), "hipMemcpy2DAsync");
+                const BandCopy c = L.copy(f, r);
+                const uint64_t *src = (r == 0 ? S.packed[0] : S.staging[(size_t)r]) + c.src;
+                hip_check(hipMemcpy2DAsync(S.frames + c.dst, c.dst_pitch * 8, src, c.src_pitch * 8, c.row_records * 8, c.rows, hipMemcpyDeviceToDevice, S.streams[0]), "hipMemcpy2DAsync");
             }
         if (slot_out) *slot_out = s;
         return S.frames;
@@ -195,9 +195,9 @@ private:
         if (w == S.width && h == S.height && frames <= S.frames_cap) return;
         wait();                                             // nothing of this slot (or the other) may still use the buffers
         release(S);                                         // (pointers are nulled: a failed hipMalloc below leaves nothing dangling)
-        const int bands_total = (h + BAND - 1) / BAND;
-        S.nb = (bands_total + n_ - 1) / n_;
-        const size_t share = (size_t)frames * (size_t)S.nb * BAND * (size_t)w;
+        const BandLayout L{ n_, w, h, frames };
+        S.nb = L.bands_per_rank();
+        const size_t share = L.share_records();
         for (int r = 0; r < n_; ++r) {
             hip_check(hipSetDevice(r), "hipSetDevice");
             hip_check(hipMalloc((void **)&S.bands[(size_t)r], share * sizeof(svo_hit)), "hipMalloc");
@@ -205,7 +205,7 @@ private:
         }
         hip_check(hipSetDevice(0), "hipSetDevice");
         for (int r = 1; r < n_; ++r) hip_check(hipMalloc((void **)&S.staging[(size_t)r], share * 8), "hipMalloc");
-        S.frame_stride = (size_t)S.nb * (size_t)n_ * BAND * (size_t)w;                      // whole rounds of bands: the last one may hang over the image
+        S.frame_stride = L.frame_stride();                  // whole rounds of bands: the last one may hang over the image
         hip_check(hipMalloc((void **)&S.frames, (size_t)frames * S.frame_stride * 8), "hipMalloc");
         S.width = w; S.height = h; S.frames_cap = frames;
     }
