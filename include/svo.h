@@ -30,7 +30,8 @@
  *
  * Conventions
  *   - plain C, opaque handle, caller owns every buffer it passes in;
- *   - every function returns an int status: SVO_OK (0) or a negative svo_status; nothing aborts
+ *   - every function returns an int status: SVO_OK (0), a positive "done, but" status (SVO_OK_LITERAL_ONLY) or a negative
+ *     svo_status (nothing was changed unless the entry point says otherwise); nothing aborts
  *     or throws across this boundary (the reference uses assert/die(), src/Util.cpp:72-78);
  *   - pointers named *_dev are DEVICE pointers (HBM of the device the world was uploaded to),
  *     all others are host pointers;
@@ -66,6 +67,11 @@ extern "C" {
 
 typedef enum svo_status {
     SVO_OK                 =  0,
+    SVO_OK_LITERAL_ONLY    =  1,   /* svo_world_upload / svo_world_generate on a device: the world IS resident;
+                                      svo_world_update / svo_world_edit_box / svo_world_shift: the change HAS been applied - every
+                                      later launch sees the new world - but the stack kernel's wide trees could not be rebuilt (out
+                                      of device memory, mostly): SVO_KERNEL_AUTO marches with the literal kernel, SVO_KERNEL_STACK is
+                                      refused, until a later update / edit / shift / upload rebuilds them.  svo_last_error() says why */
     SVO_ERR_INVALID_ARG    = -1,
     SVO_ERR_NO_DEVICE      = -2,   /* no HIP device / HIP call failed; see svo_last_error() */
     SVO_ERR_OUT_OF_MEMORY  = -3,
@@ -315,7 +321,10 @@ int svo_trace_rays(svo_world *, const float *origins_dev, const float *dirs_dev,
                    const svo_trace_params *params, svo_hit *out_dev, void *stream);
 
 /* order_dev[0..ntiles) = the tile indices sorted by descending cost[i][0] + cost[i][1] (a stable device sort; cost_dev as
- * svo_trace_params.tile_cost_dev of ONE frame wrote it).  Asynchronous on `stream`. */
+ * svo_trace_params.tile_cost_dev of ONE frame wrote it).  Asynchronous on `stream`; calls of one world on different streams are
+ * ordered behind one another on the device (they share the world's sort scratch), each call's order_dev is complete when the
+ * work issued on its own stream before reaches it.  A launch ignores entries of tile_order_dev that are not tile indices (such a
+ * tile is skipped, its pixels stay unwritten) rather than read out of range. */
 int svo_tile_order(svo_world *, const uint32_t *cost_dev, uint32_t *order_dev, int ntiles, void *stream);
 
 /* ---- packed G-buffer (8 bytes / pixel) for the multi-GPU gather ------------------------------------------

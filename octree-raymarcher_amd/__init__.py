@@ -40,6 +40,7 @@ lib = C.CDLL(LIB_PATH)
 
 # ---- enums / constants (include/svo.h) -----------------------------------------------------
 SVO_OK = 0
+OK_LITERAL_ONLY = 1     # svo_world_update / edit_box / shift: applied, but the stack kernel's wide trees could not be rebuilt
 ERR_NAMES = {0: "SVO_OK", -1: "SVO_ERR_INVALID_ARG", -2: "SVO_ERR_NO_DEVICE", -3: "SVO_ERR_OUT_OF_MEMORY",
              -4: "SVO_ERR_MALFORMED_TREE", -5: "SVO_ERR_NOT_UPLOADED", -6: "SVO_ERR_UNSUPPORTED", -7: "SVO_ERR_HIP"}
 EMPTY, LEAF, BRANCH, TWIG = 0, 1, 2, 3
@@ -412,7 +413,7 @@ class World:
 
     # -- device ----------------------------------------------------------------------------
     def upload(self, device: int = 0) -> "World":
-        _check(lib.svo_world_upload(self._h, device), "svo_world_upload")
+        self.upload_status = _check(lib.svo_world_upload(self._h, device), "svo_world_upload")     # SVO_OK or OK_LITERAL_ONLY
         return self
 
     def update(self, chunk: int, desc: dict, tree_range=(0, 0), twig_range=(0, 0), realloc: bool = False):
@@ -423,18 +424,18 @@ class World:
         d.size, d.depth = float(desc["size"]), int(desc["depth"])
         d.tree, d.trees = tree.ctypes.data_as(C.POINTER(C.c_uint32)), tree.size
         d.twig, d.twigs = twig.ctypes.data_as(C.POINTER(C.c_uint16)), twig.size // 64
-        _check(lib.svo_world_update(self._h, chunk, C.byref(d), tree_range[0], tree_range[1], twig_range[0], twig_range[1],
-                                    1 if realloc else 0), "svo_world_update")
+        return _check(lib.svo_world_update(self._h, chunk, C.byref(d), tree_range[0], tree_range[1], twig_range[0], twig_range[1],
+                                           1 if realloc else 0), "svo_world_update")
 
     def edit_box(self, chunk: int, op: int, lo, hi, material: int = 0):
         """Ocroot::build / destroy / replace + World::modify on the device (svo_world_edit_box); op = EDIT_BUILD / EDIT_DESTROY / EDIT_REPLACE."""
-        _check(lib.svo_world_edit_box(self._h, int(chunk), int(op), (C.c_float * 3)(*[float(v) for v in lo]),
-                                      (C.c_float * 3)(*[float(v) for v in hi]), C.c_uint16(int(material))), "svo_world_edit_box")
+        return _check(lib.svo_world_edit_box(self._h, int(chunk), int(op), (C.c_float * 3)(*[float(v) for v in lo]),
+                                             (C.c_float * 3)(*[float(v) for v in hi]), C.c_uint16(int(material))), "svo_world_edit_box")
 
     def shift(self, offset):
         """World::shift (src/World.cpp:334-378): slide the grid one chunk along one axis."""
         off = (C.c_int * 3)(*[int(v) for v in offset])
-        _check(lib.svo_world_shift(self._h, off), "svo_world_shift")
+        return _check(lib.svo_world_shift(self._h, off), "svo_world_shift")
 
     # raw launches on caller-owned device memory (bench.py passes torch tensors' data_ptr())
     def trace(self, cam: Camera, params: TraceParams, rect, out_ptr: int, stream: int = 0):

@@ -692,10 +692,10 @@ static int generate_world_resident_impl(svo_world &w, int device)
         (void)hipFree(trees[i]); trees[i] = nullptr;
     }
     lapt("pack + masks");
-    if ((rc = build_wide_all(w, s)) != SVO_OK) return rc;
+    const bool literal_only = build_wide_all(w, s) != SVO_OK;         // (a complete world either way: see svo_world_upload)
     lapt("wide trees");
     BUILD_TRY(hipDeviceSynchronize());
-    return SVO_OK;
+    return literal_only ? SVO_OK_LITERAL_ONLY : SVO_OK;
 }
 
 // What svo_world_shift and svo_world_edit_box keep between calls on an uploaded world (created by the first one, freed with the
@@ -737,24 +737,36 @@ static int shift_world_resident_impl(svo_world &w, int axis, int sign)
     DevicePyramidBuilder &pyr = ctx.pyr;
     DeviceGrower &grower = ctx.grower;
     DeviceFiller &filler = ctx.filler;
+    // The whole entering plane is generated before any of it is installed: a failure on the way (device memory, mostly) leaves
+    // the world as it was.  Once the installs have begun they all happen and chunkcoordmin moves - no launch sees a grid whose
+    // slots hold chunks of two positions of the window ("none sees a mixture", svo.h); a wide tree that could not be rebuilt on
+    // the way only takes the stack kernel away (SVO_OK_LITERAL_ONLY).
+    struct Entering { ChunkPools c; uint32_t *tree_dev = nullptr; uint16_t *twig_dev = nullptr; int index = 0; };
+    std::vector<Entering> plane;
+    auto release = [&plane]() { for (Entering &e : plane) { (void)hipFree(e.tree_dev); (void)hipFree(e.twig_dev); } plane.clear(); };
     for (int cz = lo[2]; cz < hi[2]; ++cz)
         for (int cx = lo[0]; cx < hi[0]; ++cx) {
             int rc = pyr.build(res, tp.amplitude, 1.0f / (float)res, (float)cx * (float)res + (float)tp.seed, tp.yshift,
                                (float)cz * (float)res + (float)tp.seed, s);
-            if (rc != SVO_OK) return rc;
+            if (rc != SVO_OK) { release(); return rc; }
             for (int cy = lo[1]; cy < hi[1]; ++cy) {
-                ChunkPools c;
+                plane.emplace_back();
+                Entering &e = plane.back();
                 const float pos[3] = { (float)cx * (float)w.chunksize, (float)cy * (float)w.chunksize, (float)cz * (float)w.chunksize };
-                uint32_t *tree_dev = nullptr;
-                uint16_t *twig_dev = nullptr;
-                rc = grower.grow(c, pos, (float)w.chunksize, tp.depth, pyr.view, tp, s, filler, &tree_dev, &twig_dev);
-                if (rc == SVO_OK) rc = install_resident_chunk(w, svo_world_index(&w, cx, cy, cz), c, tree_dev, twig_dev);
-                (void)hipFree(tree_dev); (void)hipFree(twig_dev);
-                if (rc != SVO_OK) return rc;
+                e.index = svo_world_index(&w, cx, cy, cz);
+                rc = grower.grow(e.c, pos, (float)w.chunksize, tp.depth, pyr.view, tp, s, filler, &e.tree_dev, &e.twig_dev);
+                if (rc != SVO_OK) { release(); return rc; }
             }
         }
+    int status = SVO_OK;
+    for (Entering &e : plane) {
+        const int rc = install_resident_chunk(w, e.index, e.c, e.tree_dev, e.twig_dev);
+        if (rc < 0) { release(); return rc; }       // a HIP failure in the middle of the copies: the device is in no state to go on with
+        if (rc != SVO_OK) status = rc;
+    }
+    release();
     w.chunkcoordmin[axis] += sign;
-    return SVO_OK;
+    return status;
 }
 
 int shift_world_resident(svo_world &w, int axis, int sign)
@@ -805,7 +817,7 @@ int generate_world_resident(svo_world &w, int device)
 {
     try {
         const int rc = generate_world_resident_impl(w, device);
-        if (rc != SVO_OK) release_device(w);
+        if (rc < 0) release_device(w);
         return rc;
     }
     catch (const std::bad_alloc &) { release_device(w); set_error("svo_world_generate (device builder): out of host memory"); return SVO_ERR_OUT_OF_MEMORY; }

@@ -105,11 +105,12 @@ int release_device(svo_world &w)
         (void)hipFree(w.d_mask); (void)hipFree(w.d_bmat); (void)hipFree(w.d_work);
         (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
         for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
+        if (w.sort_event) (void)hipEventDestroy((hipEvent_t)w.sort_event);
     }
     w.work_event.clear();
     w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_bmat = nullptr; w.d_work = nullptr;
     w.d_wide = nullptr; w.d_wbase = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
-    w.d_sort = nullptr; w.sort_bytes = 0;
+    w.d_sort = nullptr; w.sort_bytes = 0; w.sort_event = nullptr;
     w.device = -1;
     w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear(); w.wtable.clear(); w.wide_slot.clear();
     w.tree_pool_len = w.twig_pool_len = w.tree_pool_cap = w.twig_pool_cap = 0;
@@ -118,17 +119,19 @@ int release_device(svo_world &w)
 }
 
 // Persistent grid = the waves the kernel can keep resident (occupancy query), never more than tiles / tiles_per_wave.
-template <int MAXLV>
+template <int MAXLV, bool BIG>
 static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
 {
-    auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES>;
+    auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES, BIG>;
     if (w->occupancy_blocks <= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, w->device) != hipSuccess) return SVO_ERR_HIP;
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
         w->occupancy_blocks = prop.multiProcessorCount * per_cu;
-        if (const char *cap = std::getenv("SVO_GRID_WAVES_PER_CU")) { const int c = std::atoi(cap); if (c > 0) w->occupancy_blocks = prop.multiProcessorCount * std::min(c, per_cu); }     // experiments
+#ifdef SVO_TEST_HOOKS
+        if (const char *cap = std::getenv("SVO_GRID_WAVES_PER_CU")) { const int c = std::atoi(cap); if (c > 0) w->occupancy_blocks = prop.multiProcessorCount * std::min(c, per_cu); }     // experiments (scripts/sweep_grid.sh)
+#endif
     }
     const int64_t per_wave = tiles_per_wave > 1 ? tiles_per_wave : 1;
     const int64_t tiles = (int64_t)A.ntiles * (A.nframes > 0 ? A.nframes : 1);
@@ -330,11 +333,16 @@ static void drop_wide_scratch(svo_world &w, bool failed = true)
     if (w.d_wscratch) { (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; }
     w.wscratch_words = 0;
 }
-// test hook: SVO_TEST_FAIL_WIDE=1 makes the next wide-tree build fail as an allocation failure would
+// test hook (the `hooks` variant of the Makefile only; the shipped library reads no such variable): SVO_TEST_FAIL_WIDE=1 makes
+// the next wide-tree build fail as an allocation failure would
 static bool wide_fault_injected()
 {
+#ifdef SVO_TEST_HOOKS
     const char *e = std::getenv("SVO_TEST_FAIL_WIDE");
     return e && e[0] == '1';
+#else
+    return false;
+#endif
 }
 
 int build_wide_all(svo_world &w, void *stream)
@@ -368,7 +376,7 @@ int build_wide_all(svo_world &w, void *stream)
         used += count;
     }
     const uint64_t cap = cur + cur / 16 + 64;
-    if (cap * 64 >= (1ull << 30)) { drop_wide_scratch(w); return SVO_OK; }    // 32-bit byte offsets into the pool: literal kernel
+    if (cap >= (1ull << 32)) { drop_wide_scratch(w); return SVO_OK; }         // wide node indices are 32-bit (1 TiB of wide nodes): literal kernel
     if (hipMalloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&w.d_wbase, cap * WIDE_BASE_WORDS * sizeof(uint32_t)) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w);
@@ -460,6 +468,7 @@ static int world_upload_impl(svo_world *w, int device, bool force = false)
     w->tree_pool_len = tl; w->twig_pool_len = bl; w->tree_pool_cap = tc; w->twig_pool_cap = bc;
 
     const size_t n = w->chunks.size();
+    bool literal_only = false;
     do {
         if ((rc = alloc_pools(*w, device)) != SVO_OK) break;
         for (size_t i = 0; i < n && rc == SVO_OK; ++i) {
@@ -470,13 +479,15 @@ static int world_upload_impl(svo_world *w, int device, bool force = false)
                 hipMemcpy(w->d_twig + e.twig_off * TWIG_WORDS, c.twig.data(), c.twig.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) rc = SVO_ERR_HIP;
             if (rc == SVO_OK) rc = launch_masks(*w, e.twig_off, c.twig_count(), nullptr);
         }
-        if (rc == SVO_OK) rc = build_wide_all(*w, nullptr);
         if (rc != SVO_OK) { if (rc == SVO_ERR_HIP) set_error("svo_world_upload: copy failed"); break; }
+        // the stack kernel's wide trees: a failure here (device memory, mostly) leaves a complete world for the literal kernel
+        // (build_wide_all has dropped whatever it had begun), and the caller is told so
+        literal_only = build_wide_all(*w, nullptr) != SVO_OK;
         if (hipMemcpy(w->d_chunks, w->table.data(), n * sizeof(DevChunk), hipMemcpyHostToDevice) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess) { set_error("svo_world_upload: chunk table copy failed"); rc = SVO_ERR_HIP; break; }
     } while (0);
     if (rc != SVO_OK) { release_device(*w); return rc; }
-    return SVO_OK;
+    return literal_only ? SVO_OK_LITERAL_ONLY : SVO_OK;
 }
 
 static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc,
@@ -544,10 +555,12 @@ static int world_update_impl(svo_world *w, int chunk, const svo_chunk_desc *desc
     }
     if (table_dirty) HIP_TRY(hipMemcpy(w->d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
     // the stack kernel's view of the chunk: rebuilt from the node words now in the pool
+    // (the pools and the chunk table already hold the new chunk: a wide tree that cannot be rebuilt - rebuild_wide_chunk has dropped
+    // the wide pool then - leaves a world the literal kernel marches, and the caller is told so instead of being told "error"
+    // about a change that took effect)
     rc = rebuild_wide_chunk(*w, chunk, nullptr);
-    if (rc != SVO_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    return SVO_OK;
+    return rc == SVO_OK ? SVO_OK : SVO_OK_LITERAL_ONLY;
 }
 
 // nothing throws across the C ABI: host-side allocations of the two entry points above are fenced here
@@ -616,10 +629,9 @@ int install_resident_chunk(svo_world &w, int chunk, const ChunkPools &meta, cons
         if (rc != SVO_OK) return rc;
     }
     HIP_TRY(hipMemcpy(w.d_chunks + chunk, &e, sizeof(DevChunk), hipMemcpyHostToDevice));
-    const int rc = rebuild_wide_chunk(w, chunk, nullptr);
-    if (rc != SVO_OK) return rc;
+    const int rc = rebuild_wide_chunk(w, chunk, nullptr);      // (failure: the wide pool is dropped, the installed chunk stays - see svo_world_update)
     HIP_TRY(hipDeviceSynchronize());
-    return SVO_OK;
+    return rc == SVO_OK ? SVO_OK : SVO_OK_LITERAL_ONLY;
 }
 
 } // namespace svo
@@ -670,16 +682,26 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     return SVO_OK;
 }
 
+// The stack kernel's default instantiation addresses wide-tree entries by a 32-bit byte offset into the wide pool and brick masks by
+// a 32-bit byte offset into the mask pool (8 B per brick): pools of 2^30 entries (4 GiB; the benchmark world has 0.2 G) / 2^29 bricks
+// and more are marched by the large-world instantiation (64-bit addresses; until round 4 by the literal kernel, 5-17 times slower).
+static bool stack_needs_big(const svo_world *w)
+{
+#ifdef SVO_FORCE_WIDE64
+    return true;                    // (the `wide64` variant of the Makefile: the large-world kernel on every world, for the tests)
+#else
+    return w->wide_pool_cap * 64 >= (1ull << 30) || w->twig_pool_cap >= (1ull << 29);
+#endif
+}
+
 static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const TraceArgs &A)
 {
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
-    // the stack kernel addresses wide-tree entries by a 32-bit byte offset into the wide pool: pools of 2^30 entries and more
-    // (4 GiB; the benchmark world has 0.2 G) and chunks with 2^26 bricks or more are marched by the literal kernel
-    // (brick indices are 32-bit in the kernel, and 8 * index is too: twig_off + payload < 2^29)
-    const bool stack_ok = w->exact_geometry && w->max_levels <= (int)WIDE_MAX_LEVELS && w->wide_ok && w->twig_pool_cap < (1ull << 29);     // (step_asm.hip.h: the mask pool is addressed by a 32-bit byte offset, 8 B per brick)
+    // (brick indices and wide node indices are 32-bit in the kernel at any size: fewer than 2^32 bricks / wide nodes per world)
+    const bool stack_ok = w->exact_geometry && w->max_levels <= (int)WIDE_MAX_LEVELS && w->wide_ok && w->twig_pool_cap < (1ull << 32);
     if (want == SVO_KERNEL_LITERAL) return SVO_KERNEL_LITERAL;
     if (want == SVO_KERNEL_STACK) {
-        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 24 and a wide-tree pool below 4 GiB"); return SVO_ERR_UNSUPPORTED; }
+        if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 24 and the world's wide trees (svo_world_info.wide_nodes)"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }
@@ -711,10 +733,13 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
         if (A.tile_cost) HIP_TRY(hipMemsetAsync(A.tile_cost, 0, (size_t)A.ntiles * (size_t)(A.from_camera ? A.nframes : 1) * 2 * sizeof(uint32_t), s));
         int rc;
         const int tpw = prm ? prm->tiles_per_wave : 0, nfl = prm ? prm->launches_in_flight : 0;
-        if (w->max_levels <= 6) rc = launch_stack<6>(w, A, tpw, nfl, s);
-        else if (w->max_levels <= 10) rc = launch_stack<10>(w, A, tpw, nfl, s);
-        else if (w->max_levels <= 16) rc = launch_stack<16>(w, A, tpw, nfl, s);
-        else rc = launch_stack<22>(w, A, tpw, nfl, s);
+        // the large-world instantiation (64-bit wide-tree and mask addresses) where 32-bit offsets do not reach: two depth classes
+        // of it are compiled (a world that large is built of deep chunks)
+        if (stack_needs_big(w)) rc = w->max_levels <= 10 ? launch_stack<10, true>(w, A, tpw, nfl, s) : launch_stack<22, true>(w, A, tpw, nfl, s);
+        else if (w->max_levels <= 6) rc = launch_stack<6, false>(w, A, tpw, nfl, s);
+        else if (w->max_levels <= 10) rc = launch_stack<10, false>(w, A, tpw, nfl, s);
+        else if (w->max_levels <= 16) rc = launch_stack<16, false>(w, A, tpw, nfl, s);
+        else rc = launch_stack<22, false>(w, A, tpw, nfl, s);
         if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
     }
     HIP_TRY(hipGetLastError());
@@ -841,11 +866,18 @@ int svo_tile_order(svo_world *w, const uint32_t *cost_dev, uint32_t *order_dev, 
         if (hipMalloc(&w->d_sort, need) != hipSuccess) { set_error("svo_tile_order: hipMalloc failed"); return SVO_ERR_OUT_OF_MEMORY; }
         w->sort_bytes = need;
     }
+    // One scratch per world: calls on different streams (one cost / order pair per launch in flight is the intended use) are
+    // ordered behind one another here, like the work slots of the launches - a sort that shared its keys with another need not
+    // even yield a permutation.
+    hipEvent_t &sorted = reinterpret_cast<hipEvent_t &>(w->sort_event);
+    if (sorted) HIP_TRY(hipStreamWaitEvent(s, sorted, 0));
+    else HIP_TRY(hipEventCreateWithFlags(&sorted, hipEventDisableTiming));
     uint32_t *keys = static_cast<uint32_t *>(w->d_sort), *keys_out = keys + ntiles, *idx = keys_out + ntiles;
     void *tmp = reinterpret_cast<char *>(idx + ntiles) + ((256 - ((size_t)ntiles * 12) % 256) % 256);
     hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, cost_dev, keys, idx, ntiles);
     HIP_TRY(hipGetLastError());
     if (hipcub::DeviceRadixSort::SortPairsDescending(tmp, cub_bytes, keys, keys_out, idx, order_dev, ntiles, 0, 32, s) != hipSuccess) { set_error("svo_tile_order: sort failed"); return SVO_ERR_HIP; }
+    HIP_TRY(hipEventRecord(sorted, s));
     return SVO_OK;
 }
 

@@ -48,6 +48,8 @@
 // integer bookkeeping differ.  Divisions by powers of two (chunk edge, node edge) are written as
 // multiplications by the exact reciprocal, which is bit-identical.
 #pragma once
+#include <type_traits>
+
 #include "march.hip.h"
 #include "step_asm.hip.h"
 
@@ -250,7 +252,10 @@ __device__ __forceinline__ void note_tile_cost(int outk, uint32_t steps)
     atomicMax(&T.tile_cost[((size_t)frame * (size_t)T.ntiles + (size_t)tile) * 2 + (outk < 0 ? 1 : 0)], steps);
 }
 
-template <int MAXLV, int REFILL, int WAVES_PER_SIMD>
+// BIG: the large-world instantiation - the chunk's wide tree is a 64-bit address per lane and the brick masks are addressed with
+// 64 bits (step_asm.hip.h: march_steps_asm_big), for wide pools of 4 GiB and more and mask pools of 2^29 bricks and more; the same
+// kernel otherwise, the same results.
+template <int MAXLV, int REFILL, int WAVES_PER_SIMD, bool BIG>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
     __shared__ uint32_t stk[MAXLV / 2 + 1][64];     // wide node index per wide level of the current path (level 0 is node 0)
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifdef SVO_STACK_TIMING
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
-    unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0, n_adv = 0, n_step = 0;
+    unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0;
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
     StepStats step_stats;
     unsigned n_wsteps = 0, n_lsteps = 0, n_hit_wait = 0, n_dead_wait = 0, n_wsteps_b = 0, n_lsteps_b = 0, n_world_wait = 0, n_twig_b = 0;   // step bodies executed, marching lanes summed over them; M_HIT / M_DONE lanes summed over them
@@ -320,7 +325,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     int it_saved = 0;
     // chunk
     V3 clo = mk(0, 0, 0);
-    uint32_t wide_b = 0;            // byte offset of the chunk's top wide node in the wide pool
+    typename std::conditional<BIG, unsigned long long, uint32_t>::type wide_b = 0;   // the chunk's top wide node: byte offset into the wide pool (BIG: its address)
+    // entry `e` (64 per wide node, counted from the chunk's top wide node) of the current chunk's wide tree
+    auto ld_wide = [&](uint32_t e) -> uint32_t {
+        if constexpr (BIG) return *reinterpret_cast<const uint32_t *>((size_t)wide_b + ((size_t)e << 2));
+        else return ld_node(A.wide, wide_b + (e << 2));
+    };
     uint32_t twig_off = 0;
     int levels = 0, ci = -1;
     // descent cache: cell coordinates of the last tree step and the level of the node it ended at
@@ -355,6 +365,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     if (t < A.ntiles * A.nframes) {
                         tframe = t / A.ntiles; t -= tframe * A.ntiles;
                         t32 = (int)order[t];
+                        // the caller's array: anything that is not a tile index reads as "this entry has no tile" (an empty tile:
+                        // its 64 slots hold no ray) instead of indexing the raster or the ray list out of range
+                        if ((uint32_t)t32 >= (uint32_t)A.ntiles) { t32 = 0; tframe = -1; }
                         trow = t32 / tr_cols; tcol = t32 - trow * tr_cols;
                     }
                 }
@@ -391,14 +404,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     if (T.from_camera) {
                         const int lx = tcol * TILE_W + (lane & (TILE_W - 1));
                         const int ly = trow * TILE_H + lane / TILE_W;
-                        ok = (lx < T.w) & (ly < T.h);
+                        ok = (lx < T.w) & (ly < T.h) & (tframe >= 0);      // (tframe < 0: an entry of the caller's tile order that names no tile)
                         k = (tframe * T.h + ly) * T.w + lx;
                         int px = 0, py = 0;
                         if (ok) local_to_pixel(T, lx, ly, px, py);
                         if (ok && (py >= T.imgh || px >= T.imgw)) { store_miss(A.out, k, 0); ok = false; }
                         if (ok) camera_ray(camera_reloaded(tframe), T.imgw, T.imgh, px, py, o, d);
                     } else {
-                        ok = id < T.n;
+                        ok = id < T.n && tframe >= 0;
                         k = id;
                         if (ok) { o = ld3(T.origins + 3 * (long long)id); d = ld3(T.dirs + 3 * (long long)id); }
                     }
@@ -465,7 +478,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         // ---- chunk step: src/Traverse.cpp:142-156 -------------------------------------------
 #ifdef SVO_STACK_TIMING
         n_world_runs += run_world; n_hit_runs += run_hit;
-        n_step += __ballot(mode == M_TREE || mode == M_TWIG) != 0;
 #endif
         if (run_world && mode == M_WORLD) {
             if (cw < 0) {                               // left its chunk in the step: t += escape(chunk box) + EPS, src/Traverse.cpp:164-168
@@ -498,7 +510,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     }
                     miss = !inside(p, clo, clo + csize);
                     if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
-                        wide_b = ch_wide << 8;                       // 64 entries of 4 bytes per wide node
+                        if constexpr (BIG) wide_b = (unsigned long long)(size_t)A.wide + ((unsigned long long)ch_wide << 8);
+                        else wide_b = ch_wide << 8;                  // 64 entries of 4 bytes per wide node
                         twig_off = ch_twig;
                         levels = (int)ch_levels;
                         O = p; t = 0.0f; cnt = A.cap_tree;
@@ -534,12 +547,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifndef SVO_CXX_STEP
         // (step_asm.hip.h) the steps of this pass in one statement: 1 + fixed_steps at first, single steps while the inner repeat lasts
         const int nsteps = pass == 0 ? 1 + fixed_steps : SVO_DRAIN_STEPS;
-        march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                        beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps
 #ifdef SVO_STACK_TIMING
-                        , step_stats
+#define SVO_STEP_STATS_ARG , step_stats
+#else
+#define SVO_STEP_STATS_ARG
 #endif
-                        );
+        if constexpr (BIG)
+            march_steps_asm_big(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
+                                beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+        else
+            march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
+                            beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+#undef SVO_STEP_STATS_ARG
         pass += nsteps - 1;
 #else
         if (mode == M_TREE || mode == M_TWIG) {
@@ -585,13 +604,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(k) : "v"(keep), "v"(valid));
                     uint32_t wnode = stk[k][lane];                  // (row 0 holds node 0: no branch for k == 0)
                     int sh = 2 * (nw - 1 - k);                      // the two coordinate bits that select the entry
-                    uint32_t word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
+                    uint32_t word = ld_wide((wnode << 6) + wide_slot(ux, uy, uz, sh));
                     while (is_branch(word)) {
                         wnode = word & WIDE_PAYLOAD;
                         ++k;
                         stk[k][lane] = wnode;
                         sh -= 2;
-                        word = ld_node(A.wide, wide_b + (((wnode << 6) + wide_slot(ux, uy, uz, sh)) << 2));
+                        word = ld_wide((wnode << 6) + wide_slot(ux, uy, uz, sh));
                     }
                     valid = k; pux = ux; puy = uy; puz = uz;
                     plev = (int)((word >> 25) & 31u);               // the reference node's level: it spans 2^(levels - level) cells
@@ -828,16 +847,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         if (run_hit && mode == M_HIT) {
             // which voxel: the node comes from the descent cache; the frame still describes the level that hit
             const int nw = levels ? (levels + 1) >> 1 : 1;
-            const uint32_t at = wide_b + ((((valid > 0 ? stk[valid][lane] : 0u) << 6) + wide_slot(pux, puy, puz, 2 * (nw - 1 - valid))) << 2);
-            const uint32_t word = ld_node(A.wide, at);              // the terminal entry again (material / brick index) ...
+            const uint32_t wn = valid > 0 ? stk[valid][lane] : 0u, slot = wide_slot(pux, puy, puz, 2 * (nw - 1 - valid));
+            const uint32_t word = ld_wide((wn << 6) + slot);        // the terminal entry again (material / brick index) ...
             // ... and the reference node it stands for (svo_hit.node): the entry's wide node keeps the index of the child block it
             // expands and of its eight grandchild blocks (wide_tree.hip.h: wbase); level 0 is the chunk's root, node 0
             uint32_t node = 0u;
             if (plev != 0) {
-                const uint32_t slot = (at >> 2) & 63u;
                 const uint32_t ci = ((slot >> 1) & 1u) | ((slot >> 2) & 2u) | ((slot >> 3) & 4u);
                 const uint32_t gi = (slot & 1u) | ((slot >> 1) & 2u) | ((slot >> 2) & 4u);
-                const uint32_t *wb = A.wbase + (size_t)(at >> 8) * WIDE_BASE_WORDS;
+                size_t wnode_in_pool;                               // the wide node's index in the pool: the chunk's top wide node + wn
+                if constexpr (BIG) wnode_in_pool = (((size_t)wide_b - (size_t)A.wide) >> 8) + wn;
+                else wnode_in_pool = (wide_b >> 8) + wn;
+                const uint32_t *wb = A.wbase + wnode_in_pool * WIDE_BASE_WORDS;
                 const int level_child = 2 * valid + 1 - (2 * nw - levels);
                 node = plev == level_child ? wb[0] + ci : wb[1 + ci] + gi;
             }

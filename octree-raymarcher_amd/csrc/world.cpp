@@ -109,6 +109,7 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
     if (tp->coarse_depth != 0 && (tp->coarse_depth < TWIG_LEVELS || tp->coarse_depth >= tp->depth)) { set_error("svo_world_generate: coarse_depth must be in [2, depth)"); return SVO_ERR_INVALID_ARG; }
     const uint32_t res = tp->pyramid_resolution ? tp->pyramid_resolution : (1u << tp->depth);
     if (res & (res - 1)) { set_error("svo_world_generate: pyramid_resolution must be a power of two"); return SVO_ERR_INVALID_ARG; }
+    int status = SVO_OK;            // (SVO_OK_LITERAL_ONLY: generated on the device, resident there, but without the stack kernel's wide trees)
     try {
         svo_world *world = new svo_world();
         world->width = w; world->height = h; world->depth = d; world->chunksize = chunksize;
@@ -122,8 +123,8 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         for (int i = 0; i < 3; ++i) { p.refine_min[i] = tp->refine_min[i]; p.refine_max[i] = tp->refine_max[i]; }
         if (tp->build_device_plus1 > 0) {
             world->terrain = p;
-            const int rc = generate_world_resident(*world, tp->build_device_plus1 - 1);
-            if (rc != SVO_OK) { svo_world_destroy(world); return rc; }
+            status = generate_world_resident(*world, tp->build_device_plus1 - 1);
+            if (status < 0) { svo_world_destroy(world); return status; }
         } else {
             if (generate_world(w, h, d, chunksize, world->chunkcoordmin, p, world->chunks) != 0) {
                 delete world;
@@ -135,7 +136,7 @@ int svo_world_generate(int w, int h, int d, int chunksize, const int ccm[3],
         world->has_terrain = true;
         classify_world(*world);
         *out = world;
-        return SVO_OK;
+        return status;
     } catch (const std::bad_alloc &) {
         set_error("svo_world_generate: out of host memory");
         return SVO_ERR_OUT_OF_MEMORY;
@@ -220,7 +221,7 @@ int svo_world_shift(svo_world *w, const int offset[3])
                     d.twig = c.twig.data(); d.twigs = c.twig_count();
                     const int idx = svo_world_index(w, cx, cy, cz);
                     const int rc = svo_world_update(w, idx, &d, 0, d.trees, 0, d.twigs, 1);
-                    if (rc != SVO_OK) return rc;
+                    if (rc < 0) return rc;
                 }
             }
     } catch (const std::bad_alloc &) {

@@ -35,6 +35,7 @@ struct svo_world {
     void *builder_ctx = nullptr;                  // builder.hip: working buffers svo_world_shift / svo_world_edit_box keep between calls
     void *d_sort = nullptr;                       // svo_tile_order scratch
     size_t sort_bytes = 0;
+    void *sort_event = nullptr;                   // hipEvent_t behind the last svo_tile_order: the next one (any stream) waits for it before it reuses the scratch
     bool wide_ok = false;                         // every chunk's bricks fit the 26-bit payload
     unsigned long long *d_work = nullptr;         // WORK_SLOTS x {tile cursor, rays marched}: one slot per launch in flight
     unsigned work_next = 0, work_last = 0;        // ring cursor; slot of the most recent launch

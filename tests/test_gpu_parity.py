@@ -209,41 +209,8 @@ def test_world_update_after_edits(svo, oracle):
     W.destroy()
 
 
-def test_failed_wide_rebuild_falls_back_to_the_literal_kernel(svo, oracle, monkeypatch):
-    """a wide-tree rebuild that fails (allocation failure injected through SVO_TEST_FAIL_WIDE) must
-    not leave the world marked as having a wide pool: svo_world_update reports the error, AUTO then marches with the
-    literal kernel (and still matches the oracle over the EDITED tree), SVO_KERNEL_STACK is refused, and the next
-    successful update brings the stack kernel back."""
-    import ctypes as C
-    O = oracle.OracleWorld.generate(2, 1, 1, 128, 6)
-    W = svo.World.create([O.chunk(i) for i in range(2)], 2, 1, 1, 128)
-    W.upload(0)
-    rng = np.random.default_rng(17)
-    o, d = random_rays(rng, 6000, (0, 0, 0), (256, 128, 128))
-    assert W.info.wide_nodes > 0
-
-    def edit(lo, hi, mat):
-        dt, dw = oracle.Delta(), oracle.Delta()
-        oracle.lib.orc_build(C.byref(O.w.chunk[0]), oracle.vec3(lo), oracle.vec3(hi), mat, C.byref(dt), C.byref(dw))
-        c = O.chunk(0)
-        W.update(0, c, tree_range=(0, c["tree"].size), twig_range=(0, c["twig"].size // 64), realloc=True)
-
-    monkeypatch.setenv("SVO_TEST_FAIL_WIDE", "1")
-    with pytest.raises(svo.SvoError) as e:
-        edit((20, 60, 20), (50, 90, 50), 5)
-    assert e.value.code == -3
-    monkeypatch.delenv("SVO_TEST_FAIL_WIDE")
-    assert W.info.wide_nodes == 0 and W.info.wide_pool_bytes == 0
-    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
-    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_AUTO), want, "auto after failed rebuild")
-    with pytest.raises(svo.SvoError):
-        W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_STACK)
-    edit((100, 100, 100), (104, 104, 104), 5)                       # succeeds: full rebuild of the wide pool
-    assert W.info.wide_nodes > 0
-    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
-    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
-        assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, "after recovery")
-    W.destroy()
+# (a wide-tree rebuild that fails - fault injection - behind svo_world_update / edit_box / shift: tests/test_variants.py, `hooks`;
+# the shipped library no longer reads the injection variable)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -731,6 +698,80 @@ def test_tile_order_changes_nothing_but_the_schedule(svo, oracle, worlds):
     svo.lib.svo_stream_synchronize(None)
     assert out.to_numpy(svo.HIT_DTYPE, w * h).tobytes() == plain.tobytes()
     for b in (out, cost, order, rev):
+        b.free()
+
+
+def test_tile_order_calls_on_several_streams_and_a_bad_order(svo, oracle, worlds):
+    """(1) svo_tile_order calls of one world on different streams share the world's sort scratch: they are ordered
+    behind one another on the device, every call's result is the permutation its own cost array asks for; (2) an entry of
+    tile_order_dev that is no tile index makes the launch skip a tile - its pixels stay as they were - and never index out of
+    range; every other pixel is the plain frame's."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    W, O, lo, hi, s = worlds["grid_2x1x2_d6"]
+    ntiles = 40000                                          # a sort long enough to overlap with the next call's
+    rng = np.random.default_rng(5)
+    streams, costs, orders, keys = [], [], [], []
+    for i in range(4):
+        h = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0        # hipStreamNonBlocking
+        streams.append(h.value)
+        c = rng.integers(0, 5000, (ntiles, 2)).astype(np.uint32)
+        keys.append(c[:, 0].astype(np.int64) + c[:, 1])
+        costs.append(svo.DeviceBuffer.from_numpy(c))
+        orders.append(svo.DeviceBuffer(ntiles * 4))
+    for rep in range(3):
+        for i in range(4):
+            W.tile_order(costs[i].ptr, orders[i].ptr, ntiles, streams[i])
+    for st in streams:
+        svo.lib.svo_stream_synchronize(st)
+    for i in range(4):
+        od = orders[i].to_numpy(np.uint32, ntiles)
+        assert np.array_equal(np.sort(od), np.arange(ntiles, dtype=np.uint32)), f"stream {i}: not a permutation"
+        assert np.all(np.diff(keys[i][od]) <= 0), f"stream {i}: not by descending cost"
+        assert np.array_equal(od, np.argsort(-keys[i], kind="stable").astype(np.uint32)), f"stream {i}: not the stable order of its own costs"
+    for st in streams:
+        hip.hipStreamDestroy(ctypes.c_void_p(st))
+    for b in costs + orders:
+        b.free()
+    # (2) a corrupted order
+    cam = svo.default_camera(2, 2, 128, 200, 120)
+    w, h = cam.width, cam.height
+    tpr = (w + 7) // 8
+    nt = tpr * ((h + 7) // 8)
+    out = svo.DeviceBuffer(w * h * 32)
+    W.trace(cam, svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK), (0, 0, w, h), out.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    plain = out.to_numpy(svo.HIT_DTYPE, w * h).copy().reshape(h, w)
+    od = np.arange(nt, dtype=np.uint32)[::-1].copy()
+    lost = [int(od[3]), int(od[100])]
+    od[3] = 0xFFFFFFFF; od[100] = nt                        # two entries that name no tile: tiles `lost` are never handed out
+    bad = svo.DeviceBuffer.from_numpy(od)
+    sentinel = np.full(w * h * 32, 0xAB, np.uint8)
+    out2 = svo.DeviceBuffer.from_numpy(sentinel)
+    W.trace(cam, svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK, tile_order_dev=bad.ptr), (0, 0, w, h), out2.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    got = out2.to_numpy(svo.HIT_DTYPE, w * h).copy().reshape(h, w)
+    skipped = np.zeros((h, w), bool)
+    for t in lost:
+        ty, tx = divmod(t, tpr)
+        skipped[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8] = True
+    assert got[~skipped].tobytes() == plain[~skipped].tobytes()
+    assert np.all(got[skipped].view(np.uint8) == 0xAB), "pixels of the skipped tiles stay unwritten"
+    # list mode: the same guard keeps origins / dirs reads inside the list
+    o, d = random_rays(np.random.default_rng(6), 64 * 50, lo, hi)
+    od_l = np.arange(50, dtype=np.uint32); od_l[7] = 1 << 20
+    ol = svo.DeviceBuffer.from_numpy(od_l)
+    ob, db = svo.DeviceBuffer.from_numpy(o), svo.DeviceBuffer.from_numpy(d)
+    out3 = svo.DeviceBuffer.from_numpy(np.full(64 * 50 * 32, 0xAB, np.uint8))
+    W.trace_rays(ob.ptr, db.ptr, 64 * 50, svo.trace_params(kernel=svo.KERNEL_STACK, tile_order_dev=ol.ptr), out3.ptr)
+    svo.lib.svo_stream_synchronize(None)
+    g3 = out3.to_numpy(svo.HIT_DTYPE, 64 * 50)
+    want = O.trace_rays(o, d, params=oracle.make_params(), threads=8)
+    keep = np.ones(64 * 50, bool); keep[7 * 64:8 * 64] = False
+    assert_gbuffer_equal(g3[keep], want[keep], "list mode around a skipped tile")
+    assert np.all(g3[~keep].view(np.uint8) == 0xAB)
+    for b in (out, out2, out3, bad, ol, ob, db):
         b.free()
 
 
