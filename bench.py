@@ -269,17 +269,14 @@ def run(args):
     t0 = time.time()
     world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **gen_kw)
     t_gen = time.time() - t0
-    # (on this pool a plain hipMalloc behind a large hipFree stalls for ~4 s about once in ten 12-GB cycles - scripts/alloc_probe.py,
-    # nothing of this library involved; a second generation that ran into it is repeated once and the line says so)
-    gen_stalled = False
-    for attempt in range(2):
-        world.destroy()
-        t0 = time.time()
-        world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **gen_kw)
-        t_gen_warm = time.time() - t0
-        if t_gen_warm < 1.0:
-            break
-        gen_stalled = True
+    # the second generation: the library hands the first world's pools on to it (include/svo.h svo_device_cache_trim: destroy
+    # keeps the large device buffers), so it is the builder alone - until round 4 it also paid hipFree + hipMalloc of 12 GB,
+    # which on this pool stalled for ~4 s about once in ten cycles (scripts/alloc_probe.py) and was papered over by a retry here
+    world.destroy()
+    t0 = time.time()
+    world = svo.World.generate(gw, gh, gd, 128, depth, threads=gen_threads, build_device=local_rank, **gen_kw)
+    t_gen_warm = time.time() - t0
+    gen_stalled = t_gen_warm > max(2.0 * t_gen, 0.5)        # slower than the process's FIRST call: not the builder's doing (reported, not retried)
     t0 = time.time()
     world.upload(local_rank)                       # already resident where it was built: a no-op
     t_up = time.time() - t0
@@ -413,6 +410,7 @@ def run(args):
     rays_local = []
     algo_cam = None
     counters_sum = None
+    exempt_records = 0                          # records outside the stack-vs-literal comparison (SVO_ERR_FLAG in either kernel's output)
     if not multi and not args.emulate_share:
         algo_cam = []
         counters_sum = dict(node_words=0, brick_cells=0, chunk_descs=0, tree_steps=0)
@@ -438,6 +436,13 @@ def run(args):
                     err = (a16[:, 9] < 0) | (b16[:, 9] < 0)                  # flags halfword, bit 15
                     if not torch.equal(a16[~err], b16[~err]):
                         raise SystemExit(f"bench.py: stack and literal kernels disagree on path camera {ci}")
+                    # ... but they are counted, and a kernel that gives up on more than a handful of rays - or the stack kernel
+                    # giving up where the literal kernel does not - is a defect, not an exemption
+                    n_err = int(err.sum().item())
+                    n_stack_only = int(((b16[:, 9] < 0) & ~(a16[:, 9] < 0)).sum().item())
+                    exempt_records += n_err
+                    if n_err > max(8, int(1e-5 * ih * iw)) or n_stack_only:
+                        raise SystemExit(f"bench.py: {n_err} records of path camera {ci} carry SVO_ERR_FLAG ({n_stack_only} from the stack kernel alone)")
         del tmp, cnt
     else:
         for c in path:
@@ -615,7 +620,7 @@ def run(args):
                 "partition": "single" if not multi else f"8-row bands round-robin x{world_size} + RCCL gather of 8-B packed G-buffer records",
                 "ranks_seen": ranks_seen, "devices": devices,
                 "launcher": "self-spawned" if os.environ.get("SVO_BENCH_SPAWNED") else ("external" if "WORLD_SIZE" in os.environ else "single process"),
-                "world_generate_s": round(t_gen, 3), "world_generate_warm_s": round(t_gen_warm, 3), "world_generate_allocator_stall_seen": gen_stalled,
+                "world_generate_s": round(t_gen, 3), "world_generate_warm_s": round(t_gen_warm, 3), "world_generate_allocator_stall_seen": gen_stalled, "stack_vs_literal_exempt_records": exempt_records,
                 "world_generate": "on the rank's GPU (noise, mips, grow, water fill), pools left in HBM; _s = first call of the process, _warm_s = second", "world_generate_threads": gen_threads, "world_upload_s": round(t_up, 3),
             },
         }

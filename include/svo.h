@@ -62,8 +62,9 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 3           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record
-                                       3: svo_trace_params.tile_cost_dev / tile_order_dev, svo_tile_order */
+#define SVO_ABI_VERSION 4           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record
+                                       3: svo_trace_params.tile_cost_dev / tile_order_dev, svo_tile_order
+                                       4: SVO_OK_LITERAL_ONLY, svo_device_cache_trim */
 
 typedef enum svo_status {
     SVO_OK                 =  0,
@@ -372,6 +373,11 @@ int svo_trace_last_ray_count(svo_world *, void *stream, uint64_t *rays);
 int   svo_device_count(void);
 void *svo_device_alloc(size_t bytes);
 void  svo_device_free(void *p_dev);
+/* The library keeps the large device buffers of a world that is destroyed or re-packed (tree, brick, mask, material and wide
+ * pools: at most 8 buffers of 1 MiB and more per process) and hands them to the next world whose pools they fit - a caller that
+ * replaces its world pays no hipFree / hipMalloc of multi-GB buffers.  This returns them to the driver (also done by itself when
+ * an allocation fails). */
+void  svo_device_cache_trim(void);
 int   svo_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
 int   svo_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
 int   svo_stream_synchronize(void *stream);

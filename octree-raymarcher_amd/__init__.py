@@ -130,7 +130,7 @@ ABI_SYMBOLS = [
     "svo_world_index_float", "svo_world_index", "svo_world_upload", "svo_world_update",
     "svo_chunk_write", "svo_chunk_read", "svo_chunk_free", "svo_world_shift", "svo_world_edit_box", "svo_shade", "svo_shade_packed", "svo_shade_defaults", "svo_gbuffer_pack", "svo_gbuffer_unpack",
     "svo_tile_order", "svo_trace", "svo_trace_rows", "svo_trace_frames", "svo_trace_rows_frames", "svo_trace_rays", "svo_trace_last_ray_count",
-    "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_memcpy_h2d", "svo_memcpy_d2h",
+    "svo_device_count", "svo_device_alloc", "svo_device_free", "svo_device_cache_trim", "svo_memcpy_h2d", "svo_memcpy_d2h",
     "svo_stream_synchronize", "svo_last_error", "svo_abi_version",
 ]
 

@@ -16,8 +16,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #ifndef SVO_STACK_REFILL
 #define SVO_STACK_REFILL 8       // retired lanes per wave that trigger a refill (cheap: rays are staged in LDS)
@@ -96,14 +98,72 @@ static int launch_masks(svo_world &w, uint64_t first, uint64_t count, hipStream_
     return SVO_OK;
 }
 
+// ---- the large device buffers of a world (tree, brick, mask, material, wide pools, the wide builder's scratch) -------------
+// A caller that replaces its world - destroy + generate, a re-pack after an edit outgrew the pools - asks for the sizes it has
+// just given back.  hipFree + hipMalloc of multi-GB buffers is not free on every runtime (on the development pool a hipMalloc
+// behind a large hipFree stalled for ~4 s about once in ten 12-GB cycles, scripts/alloc_probe.py), so buffers of 1 MiB and more
+// go to a small per-process cache instead of back to the driver and are handed out again to requests they fit (best fit, at
+// most 25 % + 1 MiB larger than asked for).  At most POOL_CACHE_SLOTS buffers are held; svo_device_cache_trim() returns them.
+constexpr size_t POOL_CACHE_SLOTS = 8, POOL_CACHE_MIN = 1u << 20;
+struct PoolBuf { void *p; size_t bytes; int device; };
+static std::mutex g_pool_mutex;
+static std::vector<PoolBuf> g_pool_live, g_pool_cache;      // what pool_malloc has handed out / what pool_free has kept
+
+static hipError_t pool_malloc(void **out, size_t bytes, int device)
+{
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t best = g_pool_cache.size();
+        for (size_t i = 0; i < g_pool_cache.size(); ++i) {
+            const PoolBuf &b = g_pool_cache[i];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + POOL_CACHE_MIN && (best == g_pool_cache.size() || b.bytes < g_pool_cache[best].bytes)) best = i;
+        }
+        if (best != g_pool_cache.size()) {
+            *out = g_pool_cache[best].p;
+            g_pool_live.push_back(g_pool_cache[best]);
+            g_pool_cache.erase(g_pool_cache.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {                                  // the cache may be what stands in the way: give it back and try once more
+        svo_device_cache_trim();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lock(g_pool_mutex); g_pool_live.push_back({ *out, bytes, device }); }
+    return e;
+}
+static void pool_free(void *p)
+{
+    if (!p) return;
+    PoolBuf b{ p, 0, -1 };
+    void *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t i = 0; i < g_pool_live.size(); ++i)
+            if (g_pool_live[i].p == p) { b = g_pool_live[i]; g_pool_live.erase(g_pool_live.begin() + (long)i); break; }
+        if (b.bytes >= POOL_CACHE_MIN) {
+            if (g_pool_cache.size() >= POOL_CACHE_SLOTS) {  // full: the smallest buffer makes room (the large ones are the expensive ones)
+                size_t small = 0;
+                for (size_t i = 1; i < g_pool_cache.size(); ++i) if (g_pool_cache[i].bytes < g_pool_cache[small].bytes) small = i;
+                if (g_pool_cache[small].bytes < b.bytes) { evict = g_pool_cache[small].p; g_pool_cache[small] = b; }
+                else evict = p;
+            } else g_pool_cache.push_back(b);
+        } else evict = p;
+    }
+    if (evict) (void)hipFree(evict);
+}
+
 int release_device(svo_world &w)
 {
     if (w.device >= 0) {
         (void)hipSetDevice(w.device);
         free_builder_context(w);
-        (void)hipFree(w.d_chunks); (void)hipFree(w.d_tree); (void)hipFree(w.d_twig);
-        (void)hipFree(w.d_mask); (void)hipFree(w.d_bmat); (void)hipFree(w.d_work);
-        (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); (void)hipFree(w.d_wchunks); (void)hipFree(w.d_wscratch); (void)hipFree(w.d_sort);
+        (void)hipDeviceSynchronize();                       // the large buffers may be handed to another world at once: nothing may still use them
+        (void)hipFree(w.d_chunks); pool_free(w.d_tree); pool_free(w.d_twig);
+        pool_free(w.d_mask); pool_free(w.d_bmat); (void)hipFree(w.d_work);
+        pool_free(w.d_wide); pool_free(w.d_wbase); (void)hipFree(w.d_wchunks); pool_free(w.d_wscratch); (void)hipFree(w.d_sort);
         for (void *e : w.work_event) if (e) (void)hipEventDestroy((hipEvent_t)e);
         if (w.sort_event) (void)hipEventDestroy((hipEvent_t)w.sort_event);
     }
@@ -160,6 +220,15 @@ void *svo_device_alloc(size_t bytes)
     return p;
 }
 void svo_device_free(void *p) { if (p) (void)hipFree(p); }
+void svo_device_cache_trim(void)
+{
+    std::vector<PoolBuf> out;
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); out.swap(g_pool_cache); }
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (const PoolBuf &b : out) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+    if (have) (void)hipSetDevice(cur);
+}
 int svo_memcpy_h2d(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return SVO_OK; }
 int svo_memcpy_d2h(void *dst, const void *src, size_t bytes) { HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return SVO_OK; }
 int svo_stream_synchronize(void *stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SVO_OK; }
@@ -206,10 +275,10 @@ int alloc_pools(svo_world &w, int device)
     if (hipSetDevice(device) != hipSuccess) { set_error("svo_world_upload: hipSetDevice failed"); return SVO_ERR_NO_DEVICE; }
     w.device = device;
     const size_t n = w.chunks.size();
-    if (hipMalloc((void **)&w.d_tree, w.tree_pool_cap * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_twig, w.twig_pool_cap * TWIG_WORDS * sizeof(uint16_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_mask, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_bmat, w.twig_pool_cap * sizeof(uint16_t)) != hipSuccess ||
+    if (pool_malloc((void **)&w.d_tree, w.tree_pool_cap * sizeof(uint32_t), device) != hipSuccess ||
+        pool_malloc((void **)&w.d_twig, w.twig_pool_cap * TWIG_WORDS * sizeof(uint16_t), device) != hipSuccess ||
+        pool_malloc((void **)&w.d_mask, w.twig_pool_cap * sizeof(uint64_t), device) != hipSuccess ||
+        pool_malloc((void **)&w.d_bmat, w.twig_pool_cap * sizeof(uint16_t), device) != hipSuccess ||
         hipMalloc((void **)&w.d_chunks, n * sizeof(DevChunk)) != hipSuccess ||
         hipMalloc((void **)&w.d_wchunks, n * sizeof(DevWide)) != hipSuccess ||
         hipMalloc((void **)&w.d_work, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) {
@@ -304,8 +373,8 @@ static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
     const uint64_t B = largest_tree / 8 + 1;
     const uint64_t need = 2 * B + 2 * 64 * B + 2 * 64 * B + WIDE_BASE_WORDS * B + 1024;        // fronts, flags + ranks, entry references + a throw-away tree, its bases
     if (need <= w.wscratch_words) return SVO_OK;
-    if (w.d_wscratch) { (void)hipDeviceSynchronize(); (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; }
-    if (hipMalloc((void **)&w.d_wscratch, need * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipMalloc of the builder scratch failed"); return SVO_ERR_OUT_OF_MEMORY; }
+    if (w.d_wscratch) { (void)hipDeviceSynchronize(); pool_free(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; }
+    if (pool_malloc((void **)&w.d_wscratch, need * sizeof(uint32_t), w.device) != hipSuccess) { set_error("wide tree: hipMalloc of the builder scratch failed"); return SVO_ERR_OUT_OF_MEMORY; }
     w.wscratch_words = need;
     return SVO_OK;
 }
@@ -321,7 +390,8 @@ static bool wide_fits(const svo_world &w, int chunk)
 // the build pass writes them in place.  The node words must already be in the tree pool.
 static void drop_wide(svo_world &w)
 {
-    (void)hipFree(w.d_wide); (void)hipFree(w.d_wbase); w.d_wide = w.d_wbase = nullptr;
+    if (w.d_wide || w.d_wbase) (void)hipDeviceSynchronize();
+    pool_free(w.d_wide); pool_free(w.d_wbase); w.d_wide = w.d_wbase = nullptr;
     w.wide_ok = false;
     w.wide_pool_len = w.wide_pool_cap = w.wide_nodes_used = 0;
 }
@@ -330,7 +400,7 @@ static void drop_wide_scratch(svo_world &w, bool failed = true)
     // after a successful rebuild an interactive caller (one that has edited or slid the world: builder_ctx) keeps the scratch for
     // the next one; everybody else gets the ~1 GB back
     if (!failed && w.builder_ctx) return;
-    if (w.d_wscratch) { (void)hipFree(w.d_wscratch); w.d_wscratch = nullptr; }
+    if (w.d_wscratch) { (void)hipDeviceSynchronize(); pool_free(w.d_wscratch); w.d_wscratch = nullptr; }
     w.wscratch_words = 0;
 }
 // test hook (the `hooks` variant of the Makefile only; the shipped library reads no such variable): SVO_TEST_FAIL_WIDE=1 makes
@@ -377,8 +447,8 @@ int build_wide_all(svo_world &w, void *stream)
     }
     const uint64_t cap = cur + cur / 16 + 64;
     if (cap >= (1ull << 32)) { drop_wide_scratch(w); return SVO_OK; }         // wide node indices are 32-bit (1 TiB of wide nodes): literal kernel
-    if (hipMalloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&w.d_wbase, cap * WIDE_BASE_WORDS * sizeof(uint32_t)) != hipSuccess) {
+    if (pool_malloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t), w.device) != hipSuccess ||
+        pool_malloc((void **)&w.d_wbase, cap * WIDE_BASE_WORDS * sizeof(uint32_t), w.device) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w);
         set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY;
     }

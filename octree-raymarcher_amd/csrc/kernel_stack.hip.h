@@ -263,17 +263,21 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     // the chunk table (bmin, levels, wide offset, brick offset) of worlds of up to 64 chunks - the reference's default is 4x4x4 -
     // staged in LDS: the chunk step then reads it there instead of waiting for a 32-byte global load per lane (the block runs
     // in six of ten passes and a wave waits out the slowest lane's load each time)
-    __shared__ uint32_t chunk_tab[6][64];
+    // (the large-world instantiation holds 128 chunks - a 10x1x10 grid of depth-12 chunks is 68 GB of pools - for 1.5 KB more LDS
+    // per wave: 22 instead of 24 waves fit a CU's 160 KB)
+    constexpr int CHUNK_TAB = (BIG && MAXLV <= 10) ? 128 : 64;      // (the deep instantiation's descent column already takes the room)
+    __shared__ uint32_t chunk_tab[6][CHUNK_TAB];
     stk[0][threadIdx.x] = 0u;              // o, d, 1/d, world-entry t, output index (as int; -1 = no ray)
     const int lane = threadIdx.x;
     const bool want_cost = A.tile_cost != nullptr;      // (one SGPR held; the blocks below must not re-read the kernel arguments for a feature that is off)
     const int n_chunks = A.dimw * A.dimh * A.dimd;
-    const bool chunks_in_lds = n_chunks <= 64;
-    if (chunks_in_lds && lane < n_chunks) {
-        const DevWide ch = A.wchunks[lane];
-        chunk_tab[0][lane] = __float_as_uint(ch.bmin[0]); chunk_tab[1][lane] = __float_as_uint(ch.bmin[1]); chunk_tab[2][lane] = __float_as_uint(ch.bmin[2]);
-        chunk_tab[3][lane] = ch.levels; chunk_tab[4][lane] = ch.wide_off; chunk_tab[5][lane] = (uint32_t)ch.twig_off;
-    }
+    const bool chunks_in_lds = n_chunks <= CHUNK_TAB;
+    if (chunks_in_lds)
+        for (int i = lane; i < n_chunks; i += 64) {
+            const DevWide ch = A.wchunks[i];
+            chunk_tab[0][i] = __float_as_uint(ch.bmin[0]); chunk_tab[1][i] = __float_as_uint(ch.bmin[1]); chunk_tab[2][i] = __float_as_uint(ch.bmin[2]);
+            chunk_tab[3][i] = ch.levels; chunk_tab[4][i] = ch.wide_off; chunk_tab[5][i] = (uint32_t)ch.twig_off;
+        }
     __syncthreads();
 #ifdef SVO_STACK_TIMING
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(svo):
     out = subprocess.run(["nm", "-D", "--defined-only", svo.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(re.findall(r" T (svo_[a-z0-9_]+)$", out, flags=re.M)))
     assert exported == names, "exported svo_* symbols differ from the header"
-    assert svo.lib.svo_abi_version() == 3
+    assert svo.lib.svo_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(svo):

@@ -21,7 +21,7 @@ def lib_of(name):
 def test_variant_libraries_are_built_and_export_the_abi(svo):
     """CPU: every variant exists (build() made it; `make variants` here if a fresh checkout has not), exports every symbol of
     include/svo.h, and the shipped library reads none of the test hooks' environment variables."""
-    if not all(os.path.exists(lib_of(n)) for n, _ in VARIANTS):
+    if not os.environ.get("SVO_AMD_LIB"):       # (a no-op when they are up to date, like the product library's own make in conftest.py)
         subprocess.run(["make", "-j4", "-C", os.path.join(ROOT, "octree-raymarcher_amd"), "variants"], check=True, stdout=subprocess.DEVNULL)
     for name in sorted({n for n, _ in VARIANTS}):
         out = subprocess.run(["nm", "-D", "--defined-only", lib_of(name)], capture_output=True, text=True, check=True).stdout
