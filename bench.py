@@ -546,12 +546,25 @@ def run(args):
         lap(path[-1:], False)
         same = bool(torch.equal(ord_frame, ob))
         plain0, ord0 = lap([path[0]] * 8, False), lap([path[0]] * 8, True)
+        # the same frames under the GLSL twin's semantics (svo_trace_params.semantics = SVO_SEMANTICS_GLSL: shaders/Chunkmarch.glsl, the
+        # march the reference renders with - EPS 1/4096, caps 256 / 512 / 64, the BIGEPS guard: no ray creeps by EPS along a lattice
+        # plane).  Another march, other records: reported next to the headline semantics (src/Traverse.cpp), never instead of it.
+        prm1 = svo.trace_params(shadow=shadow, kernel=svo.KERNEL_STACK, semantics=svo.SEMANTICS_GLSL)
+        glsl_path = lap(path, False)
+        glsl_rays = []
+        for c in path[:4]:
+            world.trace(c, prm1, (0, 0, iw, ih), ob.data_ptr(), st0.cuda_stream)
+            glsl_rays.append(world.last_ray_count(st0.cuda_stream))
         single = {
             "how": "one svo_trace per frame, serialized on one stream, every camera of the path in turn (mean) and the SURVEY camera repeated; "
                    "ordered = tiles handed out longest-first by the previous frame's tile costs, svo_tile_order's device sort included",
             "plain_ms": {"mean": round(statistics.mean(plain_path), 4), "max": round(max(plain_path), 4), "survey_camera": round(statistics.median(plain0), 4)},
             "ordered_ms": {"mean": round(statistics.mean(ord_path), 4), "max": round(max(ord_path), 4), "survey_camera": round(statistics.median(ord0), 4)},
-            "records_identical": same}
+            "records_identical": same,
+            "glsl_semantics_ms": {"mean": round(statistics.mean(glsl_path), 4), "max": round(max(glsl_path), 4),
+                                  "rays_per_frame_first_4_cameras": glsl_rays,
+                                  "note": "svo_trace_params.semantics = SVO_SEMANTICS_GLSL (the shader twin's march, parity-tested against the oracle's "
+                                          "restatement of it in tests/test_gpu_glsl.py); the headline metric stays on the CPU march's semantics"}}
         if not same:
             raise SystemExit("bench.py: tile ordering changed the G-buffer - refusing to report")
 

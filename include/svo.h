@@ -64,7 +64,7 @@ extern "C" {
 
 #define SVO_ABI_VERSION 4           /* 2: svo_trace_params.normal_mode, SVO_FACE_NORMAL, error bit in the packed record
                                        3: svo_trace_params.tile_cost_dev / tile_order_dev, svo_tile_order
-                                       4: SVO_OK_LITERAL_ONLY, svo_device_cache_trim */
+                                       4: SVO_OK_LITERAL_ONLY, svo_device_cache_trim, svo_trace_params.semantics */
 
 typedef enum svo_status {
     SVO_OK                 =  0,
@@ -184,8 +184,19 @@ typedef struct svo_trace_params {
      *                   predictor).  The records written are the same with any order. */
     uint32_t       *tile_cost_dev;
     const uint32_t *tile_order_dev;
+    int32_t  semantics;             /* which of the reference's two marches (SURVEY.md App. B lists their differences):
+                                       SVO_SEMANTICS_CPU (0): src/Traverse.cpp - what every default above quotes;
+                                       SVO_SEMANTICS_GLSL (1): shaders/Chunkmarch.glsl, the march the reference RENDERS with - eps 0 means
+                                       1/4096 (:17), step caps 0 mean 256 / 512 / 64 (:1-3), cubeEscapeDistance returns BIGEPS = 1/16 for a
+                                       distance below EPS (:107-114: no ray creeps along a lattice plane for thousands of steps), a ray from
+                                       outside enters the world only if the box lies ahead of it (tnear > 0, slabs by multiplication with
+                                       1 / dir, :116-126), no chunk containment re-check (:297-330), a LEAF hit is reported at t without the
+                                       CPU code's back-off (:263-268; svo_hit.t is then the shader's sigma), brick cells are found by
+                                       multiplying with 1 / leafsize (:201,212).  Both kernels, the oracle and its Python twin implement it */
+    int32_t  _pad_semantics;
 } svo_trace_params;
 enum { SVO_NORMAL_CUBE = 0, SVO_NORMAL_FACE = 1 };
+enum { SVO_SEMANTICS_CPU = 0, SVO_SEMANTICS_GLSL = 1 };
 
 /* G-buffer record, 32 bytes per pixel / per ray. */
 enum {

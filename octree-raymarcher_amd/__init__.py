@@ -48,6 +48,7 @@ KERNEL_AUTO, KERNEL_LITERAL, KERNEL_STACK = 0, 1, 2
 EDIT_BUILD, EDIT_DESTROY, EDIT_REPLACE = 0, 1, 2     # svo_world_edit_box
 HIT_FLAG, SHADOW_TRACED, SHADOWED, FACE_NORMAL, ERR_FLAG = 1, 2, 4, 8, 1 << 15
 NORMAL_CUBE, NORMAL_FACE = 0, 1
+SEMANTICS_CPU, SEMANTICS_GLSL = 0, 1
 CELL_NONE = 0xFF
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("normal", "<f4", (3,)), ("material", "<u2"), ("flags", "<u2"),
@@ -85,7 +86,7 @@ class TraceParams(C.Structure):
                 ("max_twig_steps", C.c_int32), ("shadow", C.c_int32), ("light_dir", C.c_float * 3),
                 ("kernel", C.c_int32), ("tiles_per_wave", C.c_int32), ("counters_dev", C.c_void_p),
                 ("normal_mode", C.c_int32), ("launches_in_flight", C.c_int32),
-                ("tile_cost_dev", C.c_void_p), ("tile_order_dev", C.c_void_p)]
+                ("tile_cost_dev", C.c_void_p), ("tile_order_dev", C.c_void_p), ("semantics", C.c_int32), ("_pad_semantics", C.c_int32)]
 
 
 class Material(C.Structure):
@@ -261,8 +262,11 @@ def c5_scene() -> dict:
 
 def trace_params(shadow: bool = False, kernel: int = KERNEL_AUTO, light_dir=(1.0, -1.0, 0.0), eps: float = 0.0,
                  caps=(0, 0, 0), counters_dev: Optional[int] = None, tiles_per_wave: int = 0, normal_mode: int = 0,
-                 tile_cost_dev: Optional[int] = None, tile_order_dev: Optional[int] = None, launches_in_flight: int = 0) -> TraceParams:
+                 tile_cost_dev: Optional[int] = None, tile_order_dev: Optional[int] = None, launches_in_flight: int = 0,
+                 semantics: int = 0) -> TraceParams:
+    """semantics: SEMANTICS_CPU (src/Traverse.cpp) / SEMANTICS_GLSL (shaders/Chunkmarch.glsl); eps / caps 0 = that twin's own constants."""
     p = TraceParams()
+    p.semantics = semantics
     p.normal_mode = normal_mode
     p.eps = eps
     p.max_chunk_steps, p.max_tree_steps, p.max_twig_steps = caps
@@ -473,12 +477,13 @@ class World:
 
     # -- convenience: World::draw / chunkmarch returning numpy -------------------------------
     def draw(self, cam: Camera, rect=None, shadow: bool = False, kernel: int = KERNEL_AUTO, counters: bool = False,
-             light_dir=(1.0, -1.0, 0.0), normal_mode: int = 0):
+             light_dir=(1.0, -1.0, 0.0), normal_mode: int = 0, semantics: int = 0):
         """Trace a rectangle of the camera image; returns the G-buffer (HIT_DTYPE[h, w]) [+ counters]."""
         x0, y0, w, h = rect if rect is not None else (0, 0, cam.width, cam.height)
         out = DeviceBuffer(max(w * h, 1) * 32)
         cnt = DeviceBuffer(max(w * h, 1) * 16) if counters else None
-        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode)
+        prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode,
+                           semantics=semantics)
         self.trace(cam, prm, (x0, y0, w, h), out.ptr)
         _check(lib.svo_stream_synchronize(None), "svo_stream_synchronize")
         g = out.to_numpy(HIT_DTYPE, w * h).reshape(h, w)
@@ -490,7 +495,7 @@ class World:
         return g
 
     def chunkmarch(self, origins, dirs, shadow: bool = False, kernel: int = KERNEL_AUTO, counters: bool = False,
-                   light_dir=(1.0, -1.0, 0.0), eps: float = 0.0, caps=(0, 0, 0), normal_mode: int = 0):
+                   light_dir=(1.0, -1.0, 0.0), eps: float = 0.0, caps=(0, 0, 0), normal_mode: int = 0, semantics: int = 0):
         """chunkmarch over a ray list (src/Traverse.cpp:127-171); returns HIT_DTYPE[n] [+ counters]."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -499,7 +504,7 @@ class World:
         out = DeviceBuffer(max(n, 1) * 32)
         cnt = DeviceBuffer(max(n, 1) * 16) if counters else None
         prm = trace_params(shadow=shadow, kernel=kernel, light_dir=light_dir, eps=eps, caps=caps,
-                           counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode)
+                           counters_dev=cnt.ptr if cnt else None, normal_mode=normal_mode, semantics=semantics)
         self.trace_rays(od.ptr, dd.ptr, n, prm, out.ptr)
         _check(lib.svo_stream_synchronize(None), "svo_stream_synchronize")
         g = out.to_numpy(HIT_DTYPE, n)

@@ -179,10 +179,10 @@ int release_device(svo_world &w)
 }
 
 // Persistent grid = the waves the kernel can keep resident (occupancy query), never more than tiles / tiles_per_wave.
-template <int MAXLV, bool BIG>
-static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
+template <int MAXLV, bool BIG, bool GLSL>
+static int launch_stack_as(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
 {
-    auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES, BIG>;
+    auto kernel = k_trace_stack<MAXLV, SVO_STACK_REFILL, SVO_STACK_WAVES, BIG, GLSL>;
     if (w->occupancy_blocks <= 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, w->device) != hipSuccess) return SVO_ERR_HIP;
@@ -200,6 +200,12 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, in
     const int blocks = (int)std::min<int64_t>((tiles + per_wave - 1) / per_wave, slots);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, s, A);
     return SVO_OK;
+}
+
+template <int MAXLV, bool BIG>
+static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
+{
+    return A.glsl ? launch_stack_as<MAXLV, BIG, true>(w, A, tiles_per_wave, in_flight, s) : launch_stack_as<MAXLV, BIG, false>(w, A, tiles_per_wave, in_flight, s);
 }
 
 } // namespace svo
@@ -731,10 +737,15 @@ static int fill_common(svo_world *w, const svo_trace_params *prm, TraceArgs &A)
     }
     A.chunks = w->d_chunks; A.tree = w->d_tree; A.twig = w->d_twig; A.mask = w->d_mask;
     A.wchunks = w->d_wchunks; A.wide = w->d_wide; A.wbase = w->d_wbase; A.bmat = w->d_bmat;
-    A.eps = (prm && prm->eps != 0.0f) ? prm->eps : 1.0f / 8192.0f;
-    A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
-    A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;
-    A.cap_twig = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : 1000;
+    if (prm && prm->semantics != SVO_SEMANTICS_CPU && prm->semantics != SVO_SEMANTICS_GLSL) { set_error("svo_trace: unknown semantics"); return SVO_ERR_INVALID_ARG; }
+    const bool glsl = prm && prm->semantics == SVO_SEMANTICS_GLSL;      // defaults: src/Traverse.cpp:8,54,79,142 / shaders/Chunkmarch.glsl:1-3,17
+    A.glsl = glsl ? 1 : 0;
+    A.eps = (prm && prm->eps != 0.0f) ? prm->eps : (glsl ? 1.0f / 4096.0f : 1.0f / 8192.0f);
+    A.cap_chunk = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : (glsl ? 256 : 1000);
+    A.cap_tree = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : (glsl ? 512 : 1000);
+    A.cap_twig = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : (glsl ? 64 : 1000);
+    A.guard_eps = glsl ? A.eps : -INFINITY;
+    A.leaf_back = glsl ? 0.0f : A.eps;
     A.shadow = (prm && prm->shadow) ? 1 : 0;
     A.normal_mode = (prm && prm->normal_mode == SVO_NORMAL_FACE) ? SVO_NORMAL_FACE : SVO_NORMAL_CUBE;
     float l[3] = { 1.0f, -1.0f, 0.0f };                                  // src/Main.cpp:116 (normalised below)

@@ -74,7 +74,7 @@ __device__ inline bool lit_brick(const TraceArgs &A, V3 a, V3 b, V3 g, V3 lo, fl
         if (++guard > STEP_GUARD) return false;
         const V3 p = a + b * t;
         if (!inside(p, lo, hi)) return false;
-        const V3 f = (p - lo) / voxel;
+        const V3 f = A.glsl ? (p - lo) * (1.0f / voxel) : (p - lo) / voxel;       // shaders/Chunkmarch.glsl:201,212 / src/Traverse.cpp:58
         const int ox = (int)f.x, oy = (int)f.y, oz = (int)f.z;
         if (!inside(mk((float)ox, (float)oy, (float)oz), mk(0.0f, 0.0f, 0.0f), mk(3.0f, 3.0f, 3.0f))) return false;
         const uint32_t word = (uint32_t)(oz * 16 + oy * 4 + ox);
@@ -86,7 +86,7 @@ __device__ inline bool lit_brick(const TraceArgs &A, V3 a, V3 b, V3 g, V3 lo, fl
             vox.lo = vlo; vox.size = voxel; vox.material = m; vox.cell = word;
             return true;
         }
-        const float e = escape(p, g, vlo, vlo + voxel) + A.eps;
+        const float e = guarded(escape(p, g, vlo, vlo + voxel), A.guard_eps) + A.eps;
         t += e;
         if (A.exact_geometry && e < 2.0f * A.eps) {             // a pinned step: the following ones in closed form (exact corners: the cell test is the reference's)
             const int K = lit_creep_run(a, b, g, t, vlo, voxel, A.eps, min(A.cap_twig - 1 - c, (int)(STEP_GUARD - guard)), true, lo, voxel);
@@ -126,7 +126,7 @@ __device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevC
         }
         const uint32_t type = node_type(word);
         if (type == LEAF) {
-            s = t - A.eps;
+            s = t - A.leaf_back;                                // src/Traverse.cpp:93 (t - EPS) / shaders/Chunkmarch.glsl:266 (t)
             vox.lo = lo; vox.size = size; vox.material = node_offset(word) & 0xFFFFu; vox.node = node; vox.cell = SVO_CELL_NONE;
             return true;
         }
@@ -141,7 +141,7 @@ __device__ inline bool lit_tree(const TraceArgs &A, V3 a, V3 b, V3 g, const DevC
         } else if (type == BRANCH) {
             return false;                                   // deeper than 32 levels: malformed
         }
-        const float e = escape(p, g, lo, lo + size) + A.eps;
+        const float e = guarded(escape(p, g, lo, lo + size), A.guard_eps) + A.eps;
         t += e;
         if (A.exact_geometry && type == EMPTY && e < 2.0f * A.eps) {   // a pinned step over an EMPTY node: the following ones in closed form
             const int K = lit_creep_run(a, b, g, t, lo, size, A.eps, min(A.cap_tree - 1 - i, (int)(STEP_GUARD - guard)), false, lo, size);
@@ -161,7 +161,7 @@ __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &t
     const V3 g = recip(beta);
     float t = 0.0f;
     bool hit = true;
-    if (!inside(alpha, wlo, whi)) t = enter(alpha, beta, wlo, whi, hit) + A.eps;
+    if (!inside(alpha, wlo, whi)) t = (A.glsl ? enter_glsl(alpha, g, wlo, whi, hit) : enter(alpha, beta, wlo, whi, hit)) + A.eps;
     if (!hit) return false;
     uint32_t guard = 0;
     for (int c = 0; c < A.cap_chunk; ++c) {
@@ -172,7 +172,7 @@ __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &t
         cnt.chunk_descs++;
         const DevChunk ch = A.chunks[ci];
         const V3 clo = ld3(ch.bmin), chi = clo + A.chunksize;
-        if (!inside(p, clo, chi)) return false;
+        if (!A.glsl && !inside(p, clo, chi)) return false;      // (src/Traverse.cpp:154-155; the shader has no such check: its treemarch just fails)
         float s = 0.0f;
         const float rootsize = A.chunksize;             // Ocroot::size == chunksize (checked on create)
         if (lit_tree(A, p, beta, g, ch, rootsize, s, vox, cnt, guard)) {
@@ -182,7 +182,7 @@ __device__ inline bool lit_world(const TraceArgs &A, V3 alpha, V3 beta, float &t
             return true;
         }
         if (guard > STEP_GUARD) { runaway = true; return false; }      // the tree / brick march gave up, not the reference's caps
-        t += escape(p, g, clo, chi) + A.eps;
+        t += guarded(escape(p, g, clo, chi), A.guard_eps) + A.eps;
     }
     return false;
 }

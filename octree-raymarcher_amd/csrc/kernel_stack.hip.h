@@ -255,7 +255,9 @@ __device__ __forceinline__ void note_tile_cost(int outk, uint32_t steps)
 // BIG: the large-world instantiation - the chunk's wide tree is a 64-bit address per lane and the brick masks are addressed with
 // 64 bits (step_asm.hip.h: march_steps_asm_big), for wide pools of 4 GiB and more and mask pools of 2^29 bricks and more; the same
 // kernel otherwise, the same results.
-template <int MAXLV, int REFILL, int WAVES_PER_SIMD, bool BIG>
+// GLSL: the shader twin's march (svo_trace_params.semantics = SVO_SEMANTICS_GLSL; shaders/Chunkmarch.glsl): the guarded escape
+// distance and the LEAF hit at t inside the step (step_asm.hip.h), the entry condition and the missing containment re-check here.
+template <int MAXLV, int REFILL, int WAVES_PER_SIMD, bool BIG, bool GLSL>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 {
     __shared__ uint32_t stk[MAXLV / 2 + 1][64];     // wide node index per wide level of the current path (level 0 is node 0)
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0;
+    unsigned n_lane_busy = 0;       // per lane: asm steps it entered a statement for as a marching lane; the wave's maximum is its critical path
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
     StepStats step_stats;
     unsigned n_wsteps = 0, n_lsteps = 0, n_hit_wait = 0, n_dead_wait = 0, n_wsteps_b = 0, n_lsteps_b = 0, n_world_wait = 0, n_twig_b = 0;   // step bodies executed, marching lanes summed over them; M_HIT / M_DONE lanes summed over them
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     float t0 = 0.0f;
                     if (ok) {
                         bool hit = true;
-                        if (!inside(o, wlo, whi)) t0 = enter(o, d, wlo, whi, hit) + eps;
+                        if (!inside(o, wlo, whi)) t0 = (GLSL ? enter_glsl(o, gg, wlo, whi, hit) : enter(o, d, wlo, whi, hit)) + eps;
                         rays_marched++;
                         if (!hit) { store_miss(A.out, k, 0); ok = false; }
                     }
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         if (run_world && mode == M_WORLD) {
             if (cw < 0) {                               // left its chunk in the step: t += escape(chunk box) + EPS, src/Traverse.cpp:164-168
                 cw &= ~CW_ESCAPE_PENDING;
-                tw += escape(O, g, clo, clo + csize) + eps;
+                tw += guarded(escape(O, g, clo, clo + csize), A.guard_eps) + eps;
             }
             bool miss = cw >= A.cap_chunk;
             if (!miss) {
@@ -512,8 +515,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                         clo = ld3(ch.bmin);
                         ch_levels = ch.levels; ch_wide = ch.wide_off; ch_twig = (uint32_t)ch.twig_off;
                     }
-                    miss = !inside(p, clo, clo + csize);
-                    if (!miss) {                        // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
+                    bool contained = inside(p, clo, clo + csize);
+                    // src/Traverse.cpp:154-155: a position outside the box of the chunk found for it ends the ray.  The shader has no
+                    // such check (shaders/Chunkmarch.glsl:297-330): its treemarch fails at once, and rootmarch steps on out of that box
+                    if (GLSL && !contained) tw += guarded(escape(p, g, clo, clo + csize), A.guard_eps) + eps;     // (stays M_WORLD; cw counts it)
+                    else miss = !contained;
+                    if (contained) {                    // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
                         if constexpr (BIG) wide_b = (unsigned long long)(size_t)A.wide + ((unsigned long long)ch_wide << 8);
                         else wide_b = ch_wide << 8;                  // 64 entries of 4 bytes per wide node
                         twig_off = ch_twig;
@@ -546,6 +553,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? SVO_STEP_EXTRA : 0;
         for (;;) {
 #ifdef SVO_STACK_TIMING
+        n_lane_busy += (mode == M_TREE || mode == M_TWIG) ? (pass == 0 ? 1u + (unsigned)fixed_steps : (unsigned)SVO_DRAIN_STEPS) : 0u;     // steps of the coming statement this lane starts as a marching lane (an upper bound on its own steps)
         { const int nm = __popcll(__ballot(mode == M_TREE || mode == M_TWIG)); n_wsteps += nm > 0; n_lsteps += nm; if (more) { n_wsteps_b += nm > 0; n_lsteps_b += nm; n_hit_wait += __popcll(__ballot(mode == M_HIT)); n_dead_wait += __popcll(__ballot(mode == M_DONE)); n_world_wait += __popcll(__ballot(mode == M_WORLD)); n_twig_b += __popcll(__ballot(mode == M_TWIG)); } }
 #endif
 #ifndef SVO_CXX_STEP
@@ -556,7 +564,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #else
 #define SVO_STEP_STATS_ARG
 #endif
-        if constexpr (BIG)
+        if constexpr (BIG && GLSL)
+            march_steps_asm_big_glsl(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
+                                     beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+        else if constexpr (GLSL)
+            march_steps_asm_glsl(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
+                                 beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+        else if constexpr (BIG)
             march_steps_asm_big(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
                                 beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
         else
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             if (what == S_ADVANCE || what == S_ENTER) {
                 const V3 E_lo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                 const float E_size = res * (float)(low + 1);
-                const float e = escape(p, g, E_lo, E_lo + E_size) + eps;
+                const float e = guarded(escape(p, g, E_lo, E_lo + E_size), A.guard_eps) + eps;
                 if (what == S_ADVANCE) {
                     t += e;
                     creepn = e < 2.0f * eps ? crept + 1 : 0;        // pinned on a lattice plane: see the creep block
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 }
             }
             if (what == S_HIT_LEAF) {
-                tw = tw + (t - eps);                                // src/Traverse.cpp:93,160
+                tw = tw + (t - A.leaf_back);                        // src/Traverse.cpp:93,160 (t - EPS); shaders/Chunkmarch.glsl:266 (t)
                 cnt = (int)SVO_CELL_NONE;
                 mode = M_HIT;
             }
@@ -896,7 +910,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 outk |= (int)0x80000000;
                 tw = 0.0f; cw = 0; guard = 0; creepn = 0;
                 bool hit = true;
-                if (!inside(alpha, wlo, whi)) tw = enter(alpha, beta, wlo, whi, hit) + eps;
+                if (!inside(alpha, wlo, whi)) tw = (GLSL ? enter_glsl(alpha, g, wlo, whi, hit) : enter(alpha, beta, wlo, whi, hit)) + eps;
                 mode = hit ? M_WORLD : M_DONE;          // a shadow ray that misses the world box stays "lit"
                 rays_marched++;
             }
@@ -907,12 +921,15 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
     if (lane == 0 && total) atomicAdd(&A.work[1], (unsigned long long)total);
 #ifdef SVO_STACK_TIMING
+    (void)n_creep_steps;
+    unsigned busiest = n_lane_busy;
+    for (int off = 32; off > 0; off >>= 1) busiest = max(busiest, (unsigned)__shfl_xor((int)busiest, off, 64));
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 1] = e;
-        uint4 f; f.x = n_creep_runs; f.y = n_creep_steps; f.z = n_creep_rounds; f.w = n_dbg;
+        uint4 f; f.x = n_creep_runs; f.y = busiest; f.z = n_creep_rounds; f.w = n_dbg;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 2] = f;
         uint4 h; h.x = n_wsteps; h.y = n_lsteps; h.z = n_hit_wait; h.w = n_dead_wait;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 3] = h;

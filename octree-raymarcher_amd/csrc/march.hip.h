@@ -41,6 +41,22 @@ __device__ __forceinline__ float escape(V3 a, V3 g, V3 lo, V3 hi)
     return gmin(tx, gmin(ty, tz));
 }
 
+// The GLSL twin's guard (shaders/Chunkmarch.glsl:107-114: `return d < EPS ? BIGEPS : d`); thr = -inf switches it off (NaN: kept).
+constexpr float GLSL_BIGEPS = 0.0625f;
+__device__ __forceinline__ float guarded(float d, float thr) { return d < thr ? GLSL_BIGEPS : d; }
+
+// cubeEnterDistance, shaders/Chunkmarch.glsl:116-126: slabs by multiplication with g = 1/b, and the box must lie ahead.
+__device__ __forceinline__ float enter_glsl(V3 a, V3 g, V3 lo, V3 hi, bool &hit)
+{
+    const V3 t0 = (lo - a) * g, t1 = (hi - a) * g;
+    const float n0 = gmin(t0.x, t1.x), n1 = gmin(t0.y, t1.y), n2 = gmin(t0.z, t1.z);
+    const float f0 = gmax(t0.x, t1.x), f1 = gmax(t0.y, t1.y), f2 = gmax(t0.z, t1.z);
+    const float tnear = gmax(gmax(n0, n1), n2);
+    const float tfar = gmin(gmin(f0, f1), f2);
+    hit = (tfar > tnear) & (tnear > 0.0f);
+    return tnear;
+}
+
 // intersectCube, src/Traverse.cpp:115-125 (true divisions, not the reciprocal).
 __device__ __forceinline__ float enter(V3 a, V3 b, V3 lo, V3 hi, bool &hit)
 {

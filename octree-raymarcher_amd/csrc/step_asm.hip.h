@@ -62,30 +62,63 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
     const uint64_t *mask;
 };
 
-// ---- variant 1: 32-bit offsets against scalar bases
+// The statement's variants (step_asm_body.inc is included once per variant):
+//   addressing   32-bit offsets against scalar bases / 64-bit addresses (entry: index * 4 + the lane's wide-tree address; mask:
+//                brick index * 8 + the pool's address; the carry-out lands in VCC, which is dead at all three places; q64 is free
+//                there: the brick test is its only other user);
+//   semantics    the CPU march (src/Traverse.cpp) / its GLSL twin (shaders/Chunkmarch.glsl): the escape distance's guard
+//                `d < EPS ? BIGEPS : d` (:113; three instructions, q7 is free behind the per-axis maxima) and a LEAF hit at t
+//                instead of t - EPS (:266).  The entry condition, the containment re-check and the constants live outside the step.
+#define SVO_STEP_ADDR32_ENTRY "v_lshl_add_u32 %[q1], %[q1], 2, %[wb]\n\t" "global_load_dword %[w], %[q1], %[wide]\n\t"
+#define SVO_STEP_ADDR32_MASKOFF "v_lshlrev_b32 %[q6], 3, %[q6]\n\t" "s_nop 0\n\t"
+#define SVO_STEP_ADDR32_MASK "global_load_dwordx2 %[bm], %[q6], %[maskp]\n\t"
+#define SVO_STEP_ADDR64_ENTRY "v_mad_u64_u32 %[q64], vcc, %[q1], 4, %[wb]\n\t" "global_load_dword %[w], %[q64], off\n\t"
+#define SVO_STEP_ADDR64_MASKOFF "s_nop 1\n\t"
+#define SVO_STEP_ADDR64_MASK "v_mad_u64_u32 %[q64], vcc, %[q6], 8, %[maskp]\n\t" "global_load_dwordx2 %[bm], %[q64], off\n\t"
+#define SVO_STEP_CPU_LEAF "v_subrev_f32 %[q1], %[eps], %[t]\n\t"
+#define SVO_STEP_CPU_GUARD ""
+#define SVO_STEP_GLSL_LEAF "v_mov_b32 %[q1], %[t]\n\t"
+#define SVO_STEP_GLSL_GUARD "v_cmp_gt_f32 vcc, %[eps], %[r1]\n\t" "v_mov_b32 %[q7], 0x3d800000\n\t" "s_nop 0\n\t" "v_cndmask_b32 %[r1], %[r1], %[q7], vcc\n\t"
+
 #define SVO_STEP_FN march_steps_asm
 #define SVO_STEP_WIDE_T uint32_t
-#define SVO_STEP_LOAD_ENTRY "v_lshl_add_u32 %[q1], %[q1], 2, %[wb]\n\t" "global_load_dword %[w], %[q1], %[wide]\n\t"
-#define SVO_STEP_MASK_OFFSET "v_lshlrev_b32 %[q6], 3, %[q6]\n\t" "s_nop 0\n\t"
-#define SVO_STEP_LOAD_MASK "global_load_dwordx2 %[bm], %[q6], %[maskp]\n\t"
+#define SVO_STEP_LOAD_ENTRY SVO_STEP_ADDR32_ENTRY
+#define SVO_STEP_MASK_OFFSET SVO_STEP_ADDR32_MASKOFF
+#define SVO_STEP_LOAD_MASK SVO_STEP_ADDR32_MASK
+#define SVO_STEP_LEAF_DISTANCE SVO_STEP_CPU_LEAF
+#define SVO_STEP_ESCAPE_GUARD SVO_STEP_CPU_GUARD
+#include "step_asm_body.inc"
+#undef SVO_STEP_FN
+#undef SVO_STEP_LEAF_DISTANCE
+#undef SVO_STEP_ESCAPE_GUARD
+#define SVO_STEP_FN march_steps_asm_glsl
+#define SVO_STEP_LEAF_DISTANCE SVO_STEP_GLSL_LEAF
+#define SVO_STEP_ESCAPE_GUARD SVO_STEP_GLSL_GUARD
 #include "step_asm_body.inc"
 #undef SVO_STEP_FN
 #undef SVO_STEP_WIDE_T
 #undef SVO_STEP_LOAD_ENTRY
 #undef SVO_STEP_MASK_OFFSET
 #undef SVO_STEP_LOAD_MASK
-// ---- variant 2: 64-bit addresses (entry: index * 4 + the lane's wide-tree address; mask: brick index * 8 + the pool's address;
-//      the carry-out lands in VCC, which is dead at all three places; q64 is free there: the brick test is its only other user)
-#define SVO_STEP_FN march_steps_asm_big
+#define SVO_STEP_FN march_steps_asm_big_glsl
 #define SVO_STEP_WIDE_T unsigned long long
-#define SVO_STEP_LOAD_ENTRY "v_mad_u64_u32 %[q64], vcc, %[q1], 4, %[wb]\n\t" "global_load_dword %[w], %[q64], off\n\t"
-#define SVO_STEP_MASK_OFFSET "s_nop 1\n\t"
-#define SVO_STEP_LOAD_MASK "v_mad_u64_u32 %[q64], vcc, %[q6], 8, %[maskp]\n\t" "global_load_dwordx2 %[bm], %[q64], off\n\t"
+#define SVO_STEP_LOAD_ENTRY SVO_STEP_ADDR64_ENTRY
+#define SVO_STEP_MASK_OFFSET SVO_STEP_ADDR64_MASKOFF
+#define SVO_STEP_LOAD_MASK SVO_STEP_ADDR64_MASK
+#include "step_asm_body.inc"
+#undef SVO_STEP_FN
+#undef SVO_STEP_LEAF_DISTANCE
+#undef SVO_STEP_ESCAPE_GUARD
+#define SVO_STEP_FN march_steps_asm_big
+#define SVO_STEP_LEAF_DISTANCE SVO_STEP_CPU_LEAF
+#define SVO_STEP_ESCAPE_GUARD SVO_STEP_CPU_GUARD
 #include "step_asm_body.inc"
 #undef SVO_STEP_FN
 #undef SVO_STEP_WIDE_T
 #undef SVO_STEP_LOAD_ENTRY
 #undef SVO_STEP_MASK_OFFSET
 #undef SVO_STEP_LOAD_MASK
+#undef SVO_STEP_LEAF_DISTANCE
+#undef SVO_STEP_ESCAPE_GUARD
 
 } // namespace svo

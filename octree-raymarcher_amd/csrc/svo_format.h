@@ -105,6 +105,11 @@ struct TraceArgs {
     int32_t  cap_chunk, cap_tree, cap_twig;
     int32_t  shadow;
     int32_t  normal_mode;       // SVO_NORMAL_CUBE / SVO_NORMAL_FACE
+    // which twin is marched (svo_trace_params.semantics): the shader's cubeEscapeDistance returns BIGEPS for d < EPS - guard_eps is
+    // that EPS, or -inf (no distance is below it) for the CPU march; a LEAF hit is s = t - leaf_back (EPS for the CPU march, 0 for
+    // the shader)
+    int32_t  glsl;
+    float    guard_eps, leaf_back;
     float    sdir[3];           // normalize(-light_dir), computed on the host
     // outputs
     void     *out;              // svo_hit[n]

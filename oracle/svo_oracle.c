@@ -553,6 +553,18 @@ float orc_cubeEscapeDistance(vec3 a, vec3 b, vec3 cmin, vec3 cmax)              
 
 typedef struct { vec3 bmin; float size; uint64_t offset; } tree_t;                       /* Traverse.h:12-19 */
 
+/* Which twin is marched (orc_params.semantics): the CPU march of src/Traverse.cpp, or the fragment shader's,
+ * shaders/Chunkmarch.glsl.  GLSL's min / max are the same selections as GLM's (GLSL 4.30 spec 8.3: "min returns y if y < x,
+ * otherwise x; max returns y if x < y, otherwise x"); the shader precomputes gamma = 1.0 / beta once per ray
+ * (World.Fragment.glsl:166), the same quotient the CPU code forms per call. */
+#define GLSL_BIGEPS (1.0f / 16.0f)                                                        /* Chunkmarch.glsl:18 */
+static float escape_of(int glsl, float eps, vec3 a, vec3 b, vec3 cmin, vec3 cmax)
+{
+    float d = orc_cubeEscapeDistance(a, b, cmin, cmax);
+    if (glsl) d = d < eps ? GLSL_BIGEPS : d;                                             /* Chunkmarch.glsl:113 */
+    return d;
+}
+
 static tree_t traverse(vec3 p, const orc_root *root, orc_counters *cnt)                  /* Traverse.cpp:34-48 */
 {
     tree_t t = { root->position, root->size, 0 };
@@ -574,14 +586,15 @@ typedef struct {            /* what the GLSL twin calls Leaf + the ids parity is
 } voxel_t;
 
 static int twigmarch_ex(vec3 a, vec3 b, vec3 bmin, float size, float leafsize, const uint16_t *twig,
-                        float eps, int cap, float *s, voxel_t *vox, orc_counters *cnt)   /* Traverse.cpp:50-72 */
+                        float eps, int cap, int glsl, float *s, voxel_t *vox, orc_counters *cnt)   /* Traverse.cpp:50-72; Chunkmarch.glsl:190-238 */
 {
     vec3 bmax = v3adds(bmin, size);
+    float inv_leafsize = 1.0f / leafsize;                                                /* Chunkmarch.glsl:201 */
     float t = 0.0f;
     for (int c = 0; c < cap; ++c) {
         vec3 p = v3add(a, v3muls(b, t));
         if (!orc_isInsideCube(p, bmin, bmax)) return 0;
-        vec3 f = v3divs(v3sub(p, bmin), leafsize);
+        vec3 f = glsl ? v3muls(v3sub(p, bmin), inv_leafsize) : v3divs(v3sub(p, bmin), leafsize);      /* :212 / Traverse.cpp:58 */
         int ox = (int)f.x, oy = (int)f.y, oz = (int)f.z;
         if (!orc_isInsideCube(v3((float)ox, (float)oy, (float)oz), v3(0, 0, 0), v3(TWIG_SIZE - 1, TWIG_SIZE - 1, TWIG_SIZE - 1))) return 0;
         uint32_t word = twig_word((unsigned)ox, (unsigned)oy, (unsigned)oz);
@@ -593,14 +606,14 @@ static int twigmarch_ex(vec3 a, vec3 b, vec3 bmin, float size, float leafsize, c
             return 1;
         }
         vec3 leafmax = v3adds(leafmin, leafsize);
-        float escape = orc_cubeEscapeDistance(p, b, leafmin, leafmax);
+        float escape = escape_of(glsl, eps, p, b, leafmin, leafmax);
         t += escape + eps;
     }
     return 0;
 }
 
-static int treemarch_ex(vec3 a, vec3 b, const orc_root *root, float eps, int cap, int twigcap,
-                        float *s, voxel_t *vox, orc_counters *cnt)                       /* Traverse.cpp:74-113 */
+static int treemarch_ex(vec3 a, vec3 b, const orc_root *root, float eps, int cap, int twigcap, int glsl,
+                        float *s, voxel_t *vox, orc_counters *cnt)                       /* Traverse.cpp:74-113; Chunkmarch.glsl:240-295 */
 {
     vec3 rmin = root->position;
     vec3 rmax = v3adds(root->position, root->size);
@@ -613,21 +626,21 @@ static int treemarch_ex(vec3 a, vec3 b, const orc_root *root, float eps, int cap
         uint32_t word = root->tree[tree.offset];
         uint32_t type = node_type(word);
         if (type == ORC_EMPTY) {
-            float escape = orc_cubeEscapeDistance(p, b, tree.bmin, v3adds(tree.bmin, tree.size));
+            float escape = escape_of(glsl, eps, p, b, tree.bmin, v3adds(tree.bmin, tree.size));
             t += escape + eps;
         } else if (type == ORC_LEAF) {
-            *s = t - eps;
+            *s = glsl ? t : t - eps;                                                     /* Chunkmarch.glsl:266 / Traverse.cpp:93 */
             if (vox) { vox->bmin = tree.bmin; vox->size = tree.size; vox->material = (uint16_t)node_offset(word); vox->node = (uint32_t)tree.offset; vox->cell = CELL_NONE; }
             return 1;
         } else if (type == ORC_TWIG) {
             float leafsize = tree.size / (float)(1 << TWIG_LEVELS);
             if (twigmarch_ex(p, b, tree.bmin, tree.size, leafsize, root->twig + node_offset(word) * TWIG_WORDS,
-                             eps, twigcap, s, vox, cnt)) {
+                             eps, twigcap, glsl, s, vox, cnt)) {
                 *s += t;
                 if (vox) vox->node = (uint32_t)tree.offset;
                 return 1;
             }
-            float escape = orc_cubeEscapeDistance(p, b, tree.bmin, v3adds(tree.bmin, tree.size));
+            float escape = escape_of(glsl, eps, p, b, tree.bmin, v3adds(tree.bmin, tree.size));
             t += escape + eps;
         } else {
             assert(0);
@@ -648,9 +661,23 @@ float orc_intersectCube(vec3 a, vec3 b, vec3 cmin, vec3 cmax, int *intersect)   
     return tnear;
 }
 
-static int chunkmarch_core(vec3 alpha, vec3 beta, const orc_world *world, float eps, int cap, int treecap, int twigcap,
+/* cubeEnterDistance, Chunkmarch.glsl:116-126: the slabs by multiplication with gamma = 1 / b, and the box must lie ahead */
+static float glsl_enter(vec3 a, vec3 b, vec3 cmin, vec3 cmax, int *intersect)
+{
+    vec3 g = v3((float)(1.0 / (double)b.x), (float)(1.0 / (double)b.y), (float)(1.0 / (double)b.z));
+    vec3 tmin = v3mul(v3sub(cmin, a), g);
+    vec3 tmax = v3mul(v3sub(cmax, a), g);
+    vec3 t1 = v3min(tmin, tmax);
+    vec3 t2 = v3max(tmin, tmax);
+    float tnear = gmax(gmax(t1.x, t1.y), t1.z);
+    float tfar = gmin(gmin(t2.x, t2.y), t2.z);
+    *intersect = tfar > tnear && tnear > 0;
+    return tnear;
+}
+
+static int chunkmarch_core(vec3 alpha, vec3 beta, const orc_world *world, float eps, int cap, int treecap, int twigcap, int glsl,
                            float *tout, vec3 *sigma, voxel_t *vox, uint32_t *chunk_out, orc_counters *cnt)
-{                                                                                        /* Traverse.cpp:127-171 */
+{                                                                                        /* Traverse.cpp:127-171; rootmarch, Chunkmarch.glsl:297-330 */
     float chunksize = (float)world->chunksize;
     int ccmax[3] = { world->chunkcoordmin[0] + world->width, world->chunkcoordmin[1] + world->height, world->chunkcoordmin[2] + world->depth };
     vec3 chunkcoordmax = v3((float)ccmax[0], (float)ccmax[1], (float)ccmax[2]);
@@ -661,7 +688,7 @@ static int chunkmarch_core(vec3 alpha, vec3 beta, const orc_world *world, float 
     float t = 0.0f;
     int intersect = 1;
     if (!orc_isInsideCube(alpha, chunkmin, chunkmax))
-        t = orc_intersectCube(alpha, beta, chunkmin, chunkmax, &intersect) + eps;
+        t = (glsl ? glsl_enter(alpha, beta, chunkmin, chunkmax, &intersect) : orc_intersectCube(alpha, beta, chunkmin, chunkmax, &intersect)) + eps;
     if (!intersect) return 0;
 
     for (int c = 0; c < cap; ++c) {
@@ -675,17 +702,17 @@ static int chunkmarch_core(vec3 alpha, vec3 beta, const orc_world *world, float 
 
         vec3 cmin = world->chunk[i].position;
         vec3 cmax = v3adds(cmin, chunksize);
-        if (!orc_isInsideCube(p, cmin, cmax)) return 0;
+        if (!glsl && !orc_isInsideCube(p, cmin, cmax)) return 0;                         /* (the shader has no such check: its treemarch just fails) */
 
         float s = 0;
-        if (treemarch_ex(p, beta, &world->chunk[i], eps, treecap, twigcap, &s, vox, cnt)) {
+        if (treemarch_ex(p, beta, &world->chunk[i], eps, treecap, twigcap, glsl, &s, vox, cnt)) {
             t += s;
             if (sigma) *sigma = v3add(alpha, v3muls(beta, t));
             if (tout) *tout = t;
             if (chunk_out) *chunk_out = (uint32_t)i;
             return 1;
         } else {
-            float escape = orc_cubeEscapeDistance(p, beta, cmin, cmax);
+            float escape = escape_of(glsl, eps, p, beta, cmin, cmax);
             t += escape + eps;
         }
     }
@@ -696,12 +723,12 @@ static int chunkmarch_core(vec3 alpha, vec3 beta, const orc_world *world, float 
 
 int orc_treemarch(vec3 a, vec3 b, const orc_root *root, float *s)
 {
-    return treemarch_ex(a, b, root, DEFAULT_EPS, 1000, 1000, s, NULL, NULL);
+    return treemarch_ex(a, b, root, DEFAULT_EPS, 1000, 1000, 0, s, NULL, NULL);
 }
 
 int orc_chunkmarch(vec3 alpha, vec3 beta, const orc_world *world, vec3 *sigma)
 {
-    return chunkmarch_core(alpha, beta, world, DEFAULT_EPS, 1000, 1000, 1000, NULL, sigma, NULL, NULL, NULL);
+    return chunkmarch_core(alpha, beta, world, DEFAULT_EPS, 1000, 1000, 1000, 0, NULL, sigma, NULL, NULL, NULL);
 }
 
 /* cubeNormal, shaders/Chunkmarch.glsl:128-136 (EPS = the build's) */
@@ -736,22 +763,24 @@ static vec3 faceNormal(vec3 s, vec3 cmin, vec3 cmax, vec3 beta)
     return v3(k == 0 ? sgn : 0.0f, k == 1 ? sgn : 0.0f, k == 2 ? sgn : 0.0f);
 }
 
-static void params_resolve(const orc_params *prm, float *eps, int *cc, int *tc, int *wc)
+static int params_resolve(const orc_params *prm, float *eps, int *cc, int *tc, int *wc)
 {
-    *eps = (prm && prm->eps != 0.0f) ? prm->eps : DEFAULT_EPS;
-    *cc = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : 1000;
-    *tc = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : 1000;
-    *wc = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : 1000;
+    const int glsl = prm && prm->semantics == 1;                                          /* defaults: Traverse.cpp:8,54,79,142 / Chunkmarch.glsl:1-3,17 */
+    *eps = (prm && prm->eps != 0.0f) ? prm->eps : (glsl ? 1.0f / 4096.0f : DEFAULT_EPS);
+    *cc = (prm && prm->max_chunk_steps > 0) ? prm->max_chunk_steps : (glsl ? 256 : 1000);
+    *tc = (prm && prm->max_tree_steps > 0) ? prm->max_tree_steps : (glsl ? 512 : 1000);
+    *wc = (prm && prm->max_twig_steps > 0) ? prm->max_twig_steps : (glsl ? 64 : 1000);
+    return glsl;
 }
 
 int orc_chunkmarch_ex(vec3 alpha, vec3 beta, const orc_world *world, const orc_params *prm, orc_hit *hit, orc_counters *cnt)
 {
     float eps; int cc, tc, wc;
-    params_resolve(prm, &eps, &cc, &tc, &wc);
+    const int glsl = params_resolve(prm, &eps, &cc, &tc, &wc);
     voxel_t vox; memset(&vox, 0, sizeof vox);
     float t = 0; uint32_t chunk = 0;
     memset(hit, 0, sizeof *hit);
-    if (!chunkmarch_core(alpha, beta, world, eps, cc, tc, wc, &t, NULL, &vox, &chunk, cnt)) return 0;
+    if (!chunkmarch_core(alpha, beta, world, eps, cc, tc, wc, glsl, &t, NULL, &vox, &chunk, cnt)) return 0;
     hit->t = t;
     /* World.Fragment.glsl:171-175: point = alpha + beta * (sigma - EPS); normal = cubeNormal(point, leafmin, leafmax) */
     vec3 point = v3add(alpha, v3muls(beta, t - eps));

@@ -82,6 +82,11 @@ typedef struct orc_params {
     int32_t shadow;
     float   light_dir[3];
     int32_t normal_mode;          /* 0: cubeNormal (shaders/Chunkmarch.glsl:128-136); 1: the build's entered-face normal (never NaN) */
+    int32_t semantics;            /* 0: the CPU march, src/Traverse.cpp.  1: its GLSL twin, shaders/Chunkmarch.glsl - what the reference renders
+                                     with: EPS 1/4096 (:17), caps 256 / 512 / 64 (:1-3), cubeEscapeDistance returns BIGEPS = 1/16
+                                     for d < EPS (:107-114), world entry needs tnear > 0 and multiplies by 1/b (:116-126), no chunk containment
+                                     re-check (:297-330), a LEAF hit is s = t without the back-off (:263-268), the brick cell index multiplies by
+                                     1 / leafsize (:201,212) */
 } orc_params;
 
 typedef struct orc_camera {       /* identical to svo_camera */

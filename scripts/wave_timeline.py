@@ -30,6 +30,7 @@ for rep in range(3):
 e = e[c[:, 2] > 0]; f = f[c[:, 2] > 0]; h = h[c[:, 2] > 0]; st = st[c[:, 2] > 0]; c = c[c[:, 2] > 0]
 t0 = c[:, 0].min()
 stats = st.astype(np.int64).sum(axis=0)
+per_wave_asm = st.astype(np.int64)                # [steps, marching lanes summed, stalls, chased] of each wave's asm statements
 st = (c[:, 0] - t0).astype(np.int64) * 0.01      # us
 en = (c[:, 1] - t0).astype(np.int64) * 0.01
 print("waves that ran:", len(c), "kernel span %.1f us" % en.max())
@@ -39,7 +40,12 @@ it = c[:, 2].astype(np.int64)
 print("iters  p50 %d p99 %d max %d   us/iter p50 %.2f" % (np.percentile(it, 50), np.percentile(it, 99), it.max(), np.median((en - st) / it)))
 late = np.argsort(en)[-8:]
 for i in late:
-    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d lane0-steps %d dbg ent %d go %d K>0 %d sure %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1], f[i, 3] & 255, (f[i, 3] >> 8) & 255, (f[i, 3] >> 16) & 255, f[i, 3] >> 24))
+    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d busiest-lane steps %d dbg ent %d go %d K>0 %d sure %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1], f[i, 3] & 255, (f[i, 3] >> 8) & 255, (f[i, 3] >> 16) & 255, f[i, 3] >> 24))
+    print("      asm steps %d (%.1f marching lanes each; %.2f us per step over the wave's life), chunk-step runs %d, hit-block runs %d, refill rounds %d, tiles %d; step bodies after the tiles ran out: %d" % (
+        per_wave_asm[i, 0], per_wave_asm[i, 1] / max(1, per_wave_asm[i, 0]), (en[i] - st[i]) / max(1, per_wave_asm[i, 0]), e[i, 0] & 0xFFFF, e[i, 0] >> 16, e[i, 1] & 0xFFF, (e[i, 1] >> 12) & 0xFF,
+        int(h[i, 0]) - int(h[i, 4])))
+busy = f[:, 1].astype(np.int64)
+print("busiest lane's asm steps per wave: p50 %d p90 %d p99 %d max %d; waves ending last: %s" % (*np.percentile(busy, [50, 90, 99, 100]), busy[late].tolist()))
 for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
     print("t=%5d us running waves: %d" % (t, ((st <= t) & (en > t)).sum()))
 

@@ -63,7 +63,7 @@ class Terrain(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("eps", C.c_float), ("max_chunk_steps", C.c_int32), ("max_tree_steps", C.c_int32), ("max_twig_steps", C.c_int32),
-                ("shadow", C.c_int32), ("light_dir", C.c_float * 3), ("normal_mode", C.c_int32)]
+                ("shadow", C.c_int32), ("light_dir", C.c_float * 3), ("normal_mode", C.c_int32), ("semantics", C.c_int32)]
 
 
 class OCamera(C.Structure):
@@ -112,9 +112,11 @@ def vec3(v) -> Vec3:
     return Vec3(float(v[0]), float(v[1]), float(v[2]))
 
 
-def make_params(shadow=False, light_dir=(1.0, -1.0, 0.0), eps=0.0, caps=(0, 0, 0), normal_mode=0) -> Params:
+def make_params(shadow=False, light_dir=(1.0, -1.0, 0.0), eps=0.0, caps=(0, 0, 0), normal_mode=0, semantics=0) -> Params:
+    """semantics: 0 = the CPU march (src/Traverse.cpp), 1 = its GLSL twin (shaders/Chunkmarch.glsl); eps / caps 0 = that twin's own."""
     p = Params()
     p.normal_mode = normal_mode
+    p.semantics = semantics
     p.eps = eps
     p.max_chunk_steps, p.max_tree_steps, p.max_twig_steps = caps
     p.shadow = 1 if shadow else 0

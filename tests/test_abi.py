@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(svo):
 
 
 def test_struct_layouts_match_the_header(svo):
-    assert C.sizeof(svo.ChunkDesc) == 56 and C.sizeof(svo.Camera) == 64 and C.sizeof(svo.TraceParams) == 72
+    assert C.sizeof(svo.ChunkDesc) == 56 and C.sizeof(svo.Camera) == 64 and C.sizeof(svo.TraceParams) == 80
     assert C.sizeof(svo.TerrainParams) == 68 and svo.HIT_DTYPE.itemsize == 32
     # compile a C translation unit against the header and print the same sizes
     src = r'''#include "svo.h"

@@ -231,6 +231,42 @@ def test_multi_chunk_worlds_every_field(oracle, w, h, d, depth, ccm):
     assert_records_identical(got, want, "chunk-face creep")
 
 
+@pytest.mark.parametrize("w,h,d,depth,ccm", [(1, 1, 1, 8, (0, 0, 0)), (2, 1, 2, 6, (-1, 0, -1))])
+def test_glsl_twin_every_field(oracle, w, h, d, depth, ccm):
+    """svo_trace_params.semantics = SVO_SEMANTICS_GLSL: the march of shaders/Chunkmarch.glsl (EPS 1/4096, caps 256 / 512 / 64, the
+    BIGEPS guard, tnear > 0 at the world entry, no containment re-check, LEAF hits at t) restated twice as well - same lists as
+    the CPU march, every field and the counters; and the two twins do differ where SURVEY.md App. B says they do."""
+    O = oracle.OracleWorld.generate(w, h, d, 128, depth, chunkcoordmin=ccm)
+    P = py_world_of(O, w * h * d, w, h, d, ccm)
+    lo = np.array(ccm, np.float64) * 128
+    hi = lo + np.array([w, h, d]) * 128
+    rng = np.random.default_rng(23)
+    lists = {"random": random_rays(rng, 2500, lo, hi), "adversarial": adversarial_rays(rng, 600, lo, hi),
+             "creeping": creeping_rays(rng, 300, lo, hi, 128.0 / 2 ** depth), "creeping on chunk faces": creeping_rays(rng, 200, lo, hi, 1.0, chunk_faces=True)}
+    for name, (o, dirs) in lists.items():
+        want, wcnt = O.trace_rays(o, dirs, params=oracle.make_params(shadow=True, semantics=1), counters=True)
+        rays_c = O.last_rays
+        got, cnt, rays = pyo.trace_rays(P, o, dirs, counters=True, shadow=True, semantics=1)
+        assert_records_identical(got, want, f"GLSL {name}")
+        assert np.array_equal(cnt, wcnt) and rays == rays_c, name
+        assert wcnt[:, 3].max() <= 2 * 256 * 512 and wcnt[:, 2].max() <= 2 * 256      # the shader's caps (primary + shadow ray)
+        if name.startswith("creeping"):
+            cpu, ccnt = O.trace_rays(o, dirs, params=oracle.make_params(shadow=True, caps=(1000, 200, 60)), counters=True)
+            # the guard at work: a pinned ray advances by BIGEPS = 1/16 per step, not by EPS
+            assert (ccnt[:, 3] >= 200).sum() > 5 and wcnt[:, 3].astype(np.int64).sum() < ccnt[:, 3].astype(np.int64).sum() // 2, (wcnt[:, 3].sum(), ccnt[:, 3].sum())
+    # explicit constants override the twin's own; a world seen from outside with the box BEHIND the ray: the CPU march enters it
+    # (tfar > tnear alone, src/Traverse.cpp:123), the shader does not (tnear > 0, shaders/Chunkmarch.glsl:124)
+    o, dirs = lists["random"]
+    want = O.trace_rays(o[:600], dirs[:600], params=oracle.make_params(shadow=True, semantics=1, eps=1.0 / 1024.0, caps=(5, 40, 9)))
+    got, _ = pyo.trace_rays(P, o[:600], dirs[:600], shadow=True, semantics=1, eps=1.0 / 1024.0, caps=(5, 40, 9))
+    assert_records_identical(got, want, "GLSL, explicit eps and caps")
+    behind_o = np.array([[hi[0] + 50.0, 60.0, (lo[2] + hi[2]) / 2]], np.float32)
+    behind_d = np.array([[1.0, 0.0, 0.0]], np.float32)
+    assert oracle.OracleWorld.trace_rays(O, behind_o, behind_d, params=oracle.make_params(semantics=1))["flags"][0] == 0
+    g, _ = pyo.trace_rays(P, behind_o, behind_d, semantics=1)
+    assert g["flags"][0] == 0
+
+
 def test_python_predicates_match_c(oracle):
     rng = np.random.default_rng(3)
     L = oracle.lib

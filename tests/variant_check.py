@@ -79,6 +79,10 @@ def march(svo, ob):
         want = O.trace_rays(o, d, params=ob.make_params(shadow=True), threads=8)
         for k in kernels:
             assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"{name}/{k}")
+    for name, (o, d) in lists.items():                      # the GLSL twin's march (svo_trace_params.semantics) through the same variant
+        want = O.trace_rays(o, d, params=ob.make_params(shadow=True, semantics=1), threads=8)
+        for k in kernels:
+            assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k, semantics=svo.SEMANTICS_GLSL), want, f"GLSL {name}/{k}")
     o, d = creeping_rays(rng, 3000, lo, hi, 1.0, chunk_faces=True)
     want = O.trace_rays(o, d, params=ob.make_params(shadow=True, caps=(6, 40, 30)), threads=8)
     for k in kernels:
@@ -95,7 +99,7 @@ def march(svo, ob):
     for k in kernels:
         assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"mixed depths/{k}")
     W.destroy()
-    print("march: goldens, C1 image (both normal modes, 2 frames per launch), random / adversarial / creeping lists, mixed depths: all equal to the oracle")
+    print("march: goldens, C1 image (both normal modes, 2 frames per launch), random / adversarial / creeping lists (CPU and GLSL semantics), mixed depths: all equal to the oracle")
 
 
 def hooks(svo, ob):
