@@ -662,6 +662,8 @@ def run(args):
                 "traffic_kind": "L2-miss fabric bytes per launch (FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, so an upper bound on HBM bytes)",
                 "traffic_source": prof.get("source", "none") + " (replayed, not measured in this run)",
                 "l2_hit_rate": prof.get("l2_hit_rate"),
+                # what the memory system really moves against the chip's peak: the profiled fabric bytes per frame over THIS run's time per frame
+                "hbm_frac_measured": round(traffic / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 # the same bytes over whole-job time: what the overlapped launches deliver together
                 "achieved_throughput": round(algo_total / elapsed / 1e9, 2),
                 "frac_throughput": round(algo_total / elapsed / 1e9 / HBM_PEAK_GBS, 5),
@@ -669,6 +671,8 @@ def run(args):
                 "bytes_per_ray": round(sum(algo_cam) / sum(rays_cam), 2),
                 "kernel_ms_avg": round(kernel_ms_avg, 5), "kernel_launches_timed": reps,
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
+                "note_serialized_vs_ms_per_step": "kernel_ms_avg / frames_per_launch is the SERIALIZED launch's time per frame (its drain - the launch's longest rays - "
+                                                  "included once per launch); ms_per_step is lower because launches in flight hide each other's drain",
                 "counters_all_path_cameras": counters_sum,
             }
             if prof.get("issue"):
@@ -681,11 +685,12 @@ def run(args):
                     "instructions_per_frame": int(iss["instructions_per_frame"]), "valu_per_frame": int(iss["valu_per_frame"]), "salu_per_frame": int(iss["salu_per_frame"]),
                     "cycles_per_instruction": iss["cycles_per_instruction_weighted"], "cycles_per_instruction_spread": iss["spread_p10_p90_over_simds"],
                     "issue_utilisation_profiled_launch": iss["issue_utilisation"], "issue_utilisation_spread": iss["issue_utilisation_spread"],
+                    "issue_utilisation_direct_range": iss.get("issue_utilisation_direct_range"),
                     "issue_utilisation_this_run_at_2.4GHz": round(iss["instructions_per_frame"] * iss["cycles_per_instruction_weighted"] / simd_cycles, 4),
                     "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
-                    "note": "the kernel sits at the instruction-issue limit: 0.93 of the issue slots of a serialized 16-frame launch, its one drain included "
-                            "(0.79 for an 8-frame launch), 0.95 with launches in flight, where the drains overlap (DESIGN.md §5)"}
+                    "note": "issue_utilisation_profiled_launch is a MODEL (PMC instruction counts x the asm step's static mix priced by scripts/microbench/valu_issue); "
+                            "issue_utilisation_direct_range = the same counts priced between the cheapest class and the weighted mix: quote the range (DESIGN.md §5)"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd
