@@ -1,4 +1,6 @@
-"""One-off adversarial fuzz: stack + literal kernels vs the CPU oracle on millions of rays (GPU box)."""
+"""One-off adversarial fuzz: stack + literal kernels vs the CPU oracle on millions of rays (GPU box).
+    python scripts/fuzz_parity.py [seed [rays per case [semantics: 0 = src/Traverse.cpp, 1 = shaders/Chunkmarch.glsl]]]
+(SVO_AMD_LIB=octree-raymarcher_amd/build/libsvo_wide64.so runs the large-world instantiation of the stack kernel through it.)"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +11,7 @@ from helpers import assert_gbuffer_equal
 T = os.cpu_count() or 8
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
+SEM = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
 
 from helpers import adversarial_rays, FUZZ_CASES
@@ -28,10 +31,10 @@ for c in cases:
     o, d = rays(lo, hi, N)
     for light in ((1.0, -1.0, 0.0), (0.2, -0.9, 0.4)):
         t = time.time()
-        want = O.trace_rays(o, d, params=ob.make_params(shadow=True, light_dir=light), threads=T)
+        want = O.trace_rays(o, d, params=ob.make_params(shadow=True, light_dir=light, semantics=SEM), threads=T)
         for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
-            got = W.chunkmarch(o, d, shadow=True, kernel=k, light_dir=light)
+            got = W.chunkmarch(o, d, shadow=True, kernel=k, light_dir=light, semantics=SEM)
             assert_gbuffer_equal(got, want, f"{c} kernel {k} light {light}")
         print(c, light, "ok: rays", O.last_rays, "hits", int((want["flags"] & 1).sum()), "err flags", int((want["flags"] & 0x8000).sum()), "%.1fs" % (time.time() - t), flush=True)
     W.destroy()
-print("FUZZ OK")
+print("FUZZ OK", "semantics", SEM, "library", os.path.basename(svo.LIB_PATH))
