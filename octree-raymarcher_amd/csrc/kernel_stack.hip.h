@@ -706,154 +706,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         }
         guard += pass - 1;
 
-        // ---- creep block.  A ray that sits exactly on a lattice plane (p.a == lo.a of its cell) and moves towards the
-        //      negative side of axis a by less than one ulp per step gets cubeEscapeDistance == -0 and advances by EPS
-        //      alone (src/Traverse.cpp:25-32 has no guard against it; the GLSL twin's BIGEPS, shaders/Chunkmarch.glsl:107-114,
-        //      is not CPU semantics) - for up to thousands of steps in the same empty cell, each one a full step of the
-        //      general path.  The wave takes such steps here, in a tight loop without descent or loads, one reference step
-        //      per round: while the next position q = O + beta*t
-        //        (1) still lies in the cell located last, lo <= q < hi (tree: that is the cell the descent would find;
-        //            brick: the truncated cell index is checked as well, src/Traverse.cpp:58), which is known to be empty,
-        //        (2) is pinned, q.a == lo.a with beta.a < 0 on some axis a, and
-        //        (3) 1/beta is finite on all axes (no 0 * inf = NaN in the escape evaluation),
-        //      the reference's escape is max((lo.a-q.a)*g.a, (hi.a-q.a)*g.a) = max(-0, negative) = -0 on axis a and
-        //      >= +0 or -0 on the others, its glm::min chain yields -0, and the step is t += (-0 + EPS) = EPS, counters
-        //      included.  Anything else hands the lane back to the general step, which recomputes from the same state.
-        //      Nested creeps: a ray pinned on the lower face of a TWIG node's box creeps at the tree level (EPS per tree
-        //      step) and, inside every one of those steps, through the brick (twigmarch runs until p drops off the face,
-        //      returns false, src/Traverse.cpp:97-105): quadratically many steps.  A lane that has just entered a brick
-        //      with a creeping history asks whether the whole run of tree steps over this node consists of such misses
-        //      (brick_layer_first_touch bounds how far they can go); that run is taken at once, exactly like a run over an EMPTY node.
-        if (__ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) != 0ull) {      // (what cr and ent below need; most passes: nobody)
-            const bool cr = creepn > 0 && (mode == M_TREE || mode == M_TWIG);
-#ifdef SVO_NO_NEST
-            const bool ent = false;
-#else
-            const bool ent = mode == M_TWIG && cnt == A.cap_twig && t == 0.0f && creepn <= -4 * SVO_CREEP_SERIOUS;     // fresh in a brick after a long creep
-#endif
-            const unsigned long long crm = __ballot(cr);
-            if (eps_pow2 && (__ballot(ent) != 0ull || (crm != 0ull && (__ballot(cr && creepn >= SVO_CREEP_SERIOUS) != 0ull || __popcll(crm) >= SVO_CREEP_LANES)))) {
-                const bool twig = mode == M_TWIG && !ent;           // closed form inside a brick cell
-                const float Bsize = mode == M_TWIG ? res * 4.0f : csize, inv_res = recip_pow2(res);
-                const float finite_max = __uint_as_float(0x7F7FFFFFu);
-                bool go = (cr || ent) && (fabsf(g.x) <= finite_max) && (fabsf(g.y) <= finite_max) && (fabsf(g.z) <= finite_max);
-                // the frame the steps are taken in: the lane's own, or (ent) the tree level that entered the brick
-                const V3 fO = ent ? alpha + beta * tw : O;
-                const float ft = ent ? tt_saved : t;
-                const int kmax = ent ? it_saved + 1 : min(cnt, (int)(STEP_GUARD - guard));     // steps left under the caps
-                const V3 q0 = fO + beta * ft;                       // where the next reference step starts
-                V3 lo;
-                float fvx = 0.0f, fvy = 0.0f, fvz = 0.0f;            // brick: the cell's lattice coordinates as floats
-                float size;
-                if (ent) {                                          // the TWIG node's box == the brick frame
-                    lo = Blo; size = Bsize;
-                    go &= (q0.x == O.x) & (q0.y == O.y) & (q0.z == O.z);
-                } else if (!twig) {                                 // the EMPTY node located by the last tree step
-                    const int low = (1 << (levels - plev)) - 1;
-                    lo = mk(Blo.x + (float)(pux & ~low) * res, Blo.y + (float)(puy & ~low) * res, Blo.z + (float)(puz & ~low) * res);
-                    size = res * (float)(low + 1);
-                } else {                                            // the brick cell q0 lies in, if it is an empty one
-                    go &= inside(q0, Blo, Blo + Bsize);
-                    const int vx = (int)((q0.x - Blo.x) * inv_res), vy = (int)((q0.y - Blo.y) * inv_res), vz = (int)((q0.z - Blo.z) * inv_res);
-                    go &= (vx <= 3) & (vy <= 3) & (vz <= 3);
-                    go = go && !((bmask >> (vz * 16 + vy * 4 + vx)) & 1ull);
-                    fvx = (float)vx; fvy = (float)vy; fvz = (float)vz;
-                    lo = mk(Blo.x + fvx * res, Blo.y + fvy * res, Blo.z + fvz * res);
-                    size = res;
-                }
-                const V3 hi = lo + size;
-                // the next step itself must be a pinned one: (1) and (2) at q0
-                go &= (q0.x >= lo.x) & (q0.y >= lo.y) & (q0.z >= lo.z) & (q0.x < hi.x) & (q0.y < hi.y) & (q0.z < hi.z);
-                const bool px = (beta.x < 0.0f) & (q0.x == lo.x), py = (beta.y < 0.0f) & (q0.y == lo.y), pz = (beta.z < 0.0f) & (q0.z == lo.z);
-                go &= px | py | pz;
-#ifdef SVO_STACK_TIMING
-                ++n_creep_runs;
-#endif
-                // How many such steps follow each other?  q's components are monotone (rounded) functions of t and the
-                // ray came from inside the cell, so (1) holds for a prefix of the steps, and an axis pinned at q0 stays
-                // pinned for as long as (1) holds: "step k is a pinned step" is true for k < K and false from K on.
-                // While t_0 and EPS (a power of two) are multiples of ulp(t_k), the reference's t_k = t_{k-1} + EPS
-                // equals t_0 + k*EPS without rounding.  K is found by bit descent - 14 probes instead of K rounds -
-                // and the K steps are taken at once.
-                int K = 0;
-#ifdef SVO_STACK_TIMING
-                unsigned n_dbg_e = 0;
-#endif
-                const uint32_t t0b = __float_as_uint(ft);
-                const int e_eps = (int)(__float_as_uint(eps) >> 23);
-                bool up = true;                                     // first double the probe (short creeps end here), then descend
-                for (int b = 1; b > 0;) {
-#ifdef SVO_STACK_TIMING
-                    ++n_creep_rounds;
-#endif
-                    const int cand = up ? b : K + b;
-                    const float tk = ft + (float)(cand - 1) * eps;  // position before the cand-th step
-                    const float tn = ft + (float)cand * eps;        // parameter after it: must be exact
-                    const int e_n = (int)(__float_as_uint(tn) >> 23), shift = e_n - (int)(t0b >> 23);
-                    bool ok = go && cand <= kmax && e_n - 23 <= e_eps && tn < __uint_as_float(0x7F800000u);
-                    ok = ok && (t0b == 0u || (t0b >= 0x00800000u && shift < 24 && (((t0b & 0x007FFFFFu) | 0x00800000u) & ((1u << shift) - 1u)) == 0u));
-                    const V3 q = fO + beta * tk;
-                    ok &= (q.x >= lo.x) & (q.y >= lo.y) & (q.z >= lo.z) & (q.x < hi.x) & (q.y < hi.y) & (q.z < hi.z);
-                    if (twig) {                                     // the reference's own cell index must agree (truncation of a rounded difference)
-                        const float fx = (q.x - Blo.x) * inv_res, fy = (q.y - Blo.y) * inv_res, fz = (q.z - Blo.z) * inv_res;
-                        ok &= (fx >= fvx) & (fx < fvx + 1.0f) & (fy >= fvy) & (fy < fvy + 1.0f) & (fz >= fvz) & (fz < fvz + 1.0f);
-                    }
-                    K = ok ? cand : K;
-                    if (!up) b >>= 1;
-                    else if (__ballot(ok) == 0ull) { up = false; b >>= 2; }      // every lane: K <= b/2, bits below that are open
-                    else if (b >= (1 << 13)) { up = false; b >>= 1; }
-                    else b <<= 1;
-                }
-                if (ent) {
-                    // K tree steps over this TWIG node, each "brick march misses, t += EPS": only if every one of those
-                    // marches is a sure miss.  Then the brick is left as the reference leaves it after the K-th miss.
-                    bool sure = false;
-#ifdef SVO_STACK_TIMING
-                    n_dbg_e = 1u + (go ? 1u << 8 : 0u) + (K > 0 ? 1u << 16 : 0u);
-#endif
-                    if (K > 0) {
-                        // the marches of steps 0..K'-1 start at s <= (K'-1) EPS and last at most ulp/(2|b.k|) + EPS
-                        const int k = px ? 0 : py ? 1 : 2;
-                        const float bk = k == 0 ? Blo.x : k == 1 ? Blo.y : Blo.z, gk = k == 0 ? g.x : k == 1 ? g.y : g.z;
-                        const float tail = 0.5f * (__uint_as_float(__float_as_uint(fabsf(bk)) & 0x7F800000u) * 0x1p-23f) * fabsf(gk) + 2.0f * eps;
-                        const float room = brick_layer_first_touch(k, O, beta, g, Blo, res, bmask) - tail;
-                        if (room > 0.0f) {                          // (NaN and failed preconditions end here)
-                            const float steps = room * recip_pow2(eps);     // start points below `room`: s_j = j EPS < room
-                            const int allowed = steps >= 16384.0f ? 16384 : (int)steps + 1;
-                            K = K < allowed ? K : allowed;
-                            sure = true;
-                        }
-                    }
-#ifdef SVO_STACK_TIMING
-                    n_dbg_e += sure ? 1u << 24 : 0u;
-#endif
-                    if (sure) {
-                        t = tt_saved + (float)K * eps;
-                        cnt = it_saved - (K - 1);
-                        guard += (uint32_t)K; creepn -= K;
-                        O = fO;
-                        Blo = clo;
-                        res = csize * __uint_as_float((uint32_t)(127 - levels) << 23);
-#ifndef SVO_CXX_STEP
-                        bsize = csize;
-#endif
-                        mode = M_TREE;
-#ifdef SVO_STACK_TIMING
-                        n_creep_steps += K;
-#endif
-                    }
-                } else if (K > 0) {
-                    t += (float)K * eps;                            // == K times t + (escape + EPS) with escape == -0
-                    cnt -= K; guard += (uint32_t)K; creepn += K;
-#ifdef SVO_STACK_TIMING
-                    n_creep_steps += K;
-#endif
-                }
-#ifdef SVO_STACK_TIMING
-                for (int sh8 = 0; sh8 < 32; sh8 += 8) n_dbg += (unsigned)__popcll(__ballot((n_dbg_e >> sh8) & 1u)) << sh8;
-#endif
-            }
-        }
+#include "creep_block.inc"
 
         // ---- hits.  A shadow ray only sets a flag; a primary hit waits (M_HIT) until the wave votes to
         //      resolve: G-buffer record, then the lane becomes its own shadow ray -------------------
