@@ -172,6 +172,8 @@ lib.svo_device_alloc.argtypes = [C.c_size_t]
 lib.svo_device_alloc.restype = _P
 lib.svo_device_free.argtypes = [_P]
 lib.svo_device_free.restype = None
+lib.svo_device_cache_trim.argtypes = []
+lib.svo_device_cache_trim.restype = None
 lib.svo_memcpy_h2d.argtypes = [_P, _P, C.c_size_t]
 lib.svo_memcpy_d2h.argtypes = [_P, _P, C.c_size_t]
 lib.svo_stream_synchronize.argtypes = [_P]

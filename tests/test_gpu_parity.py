@@ -848,3 +848,38 @@ def test_sixteen_frames_per_launch_on_four_streams_against_the_oracle(svo, oracl
         hip.hipStreamDestroy(st)
     for b in bufs:
         b.free()
+
+
+def test_device_buffers_reused_between_worlds_carry_nothing_over(svo, oracle):
+    """The library keeps a destroyed world's large device buffers for the next world whose pools they fit (include/svo.h
+    svo_device_cache_trim): a world built into recycled buffers - same size, slightly smaller (the 25 % fit rule), after an edit
+    that re-packs, host-built and device-built - marches like a world built into fresh ones, and trimming in between changes nothing."""
+    rng = np.random.default_rng(77)
+    lo, hi = (0.0, 0.0, 0.0), (256.0, 128.0, 256.0)
+    o, d = random_rays(rng, 30000, lo, hi)
+
+    def check(W, seed, depth, what):
+        O = oracle.OracleWorld.generate(2, 1, 2, 128, depth, seed=seed)
+        want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+        for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+            assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"{what}/{k}")
+
+    svo.lib.svo_device_cache_trim()
+    A = svo.World.generate(2, 1, 2, 128, 8, seed=1, build_device=0)
+    check(A, 1, 8, "fresh buffers")
+    A.destroy()                                             # its pools go to the cache ...
+    B = svo.World.generate(2, 1, 2, 128, 8, seed=5, build_device=0)
+    check(B, 5, 8, "recycled buffers, other terrain")       # ... and to this world: nothing of world A may show
+    B.destroy()
+    C = svo.World.generate(2, 1, 2, 128, 8, seed=9)         # host-built, uploaded into recycled buffers
+    C.upload(0)
+    check(C, 9, 8, "recycled buffers, host-built world")
+    C.edit_box(0, svo.EDIT_BUILD, (10.0, 100.0, 10.0), (60.0, 120.0, 60.0), 5)       # (an edit on top: pools re-sent / re-packed)
+    C.destroy()
+    svo.lib.svo_device_cache_trim()                         # back to the driver: the next world allocates afresh
+    D = svo.World.generate(2, 1, 2, 128, 7, seed=5, build_device=0)
+    check(D, 5, 7, "after a trim")
+    D.destroy()
+    E = svo.World.generate(2, 1, 2, 128, 8, seed=3, build_device=0)        # larger than what D left: the cache must not hand out too small a buffer
+    check(E, 3, 8, "a larger world after a smaller one")
+    E.destroy()
