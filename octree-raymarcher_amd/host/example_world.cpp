@@ -41,6 +41,15 @@ int main(int argc, char **argv)
             svo_stream_synchronize(nullptr);
             std::printf("after build / destroy / shift: cursor moved up by %.3f\n", again.y - sigma.y);
         }
+        // the same view as the fragment shader marches it (shaders/Chunkmarch.glsl: EPS 1/4096, BIGEPS guard, LEAF hits at t)
+        world.semantics = SVO_SEMANTICS_GLSL;
+        svo::GBuffer glsl;
+        world.draw(cam, glsl, /*shadow=*/true);
+        svo_stream_synchronize(nullptr);
+        size_t ghits = 0;
+        for (const svo_hit &h : glsl.download()) ghits += (h.flags & SVO_HIT_FLAG) != 0;
+        std::printf("GLSL semantics: %zu hits\n", ghits);
+        if (ghits == 0) return 5;
         return hits > 0 ? 0 : 1;
     } catch (const svo::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code, e.what());

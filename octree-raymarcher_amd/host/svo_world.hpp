@@ -115,6 +115,10 @@ public:
 
     void load_gpu(int device = 0) { check(svo_world_upload(world_, device), "World::load_gpu"); }
 
+    // Which of the reference's two marches draw() / draw_frames() follow: the CPU code's (src/Traverse.cpp; what computeTarget and the
+    // edits use - the default) or the fragment shader's (shaders/Chunkmarch.glsl; what World::draw renders with).  SURVEY.md App. B.
+    int semantics = SVO_SEMANTICS_CPU;
+
     // World::draw: march every pixel of the camera image into `out` (asynchronous on `stream`).
     // shadow = true also casts the shadow ray of draw_shadowmap's light direction from every hit.
     void draw(const Camera &cam, GBuffer &out, bool shadow = false, const float light_dir[3] = nullptr, void *stream = nullptr)
@@ -122,6 +126,7 @@ public:
         if (out.width != cam.width || out.height != cam.height) out.resize(cam.width, cam.height);
         svo_trace_params p;
         std::memset(&p, 0, sizeof p);
+        p.semantics = semantics;
         p.shadow = shadow ? 1 : 0;
         if (light_dir) std::memcpy(p.light_dir, light_dir, sizeof p.light_dir);
         check(svo_trace(world_, &cam, &p, 0, 0, cam.width, cam.height, out.device(), stream), "World::draw");
@@ -136,6 +141,7 @@ public:
         if (out.width != w || out.height != h * (int)cams.size()) out.resize(w, h * (int)cams.size());
         svo_trace_params p;
         std::memset(&p, 0, sizeof p);
+        p.semantics = semantics;
         p.shadow = shadow ? 1 : 0;
         if (light_dir) std::memcpy(p.light_dir, light_dir, sizeof p.light_dir);
         std::vector<svo_camera> plain(cams.begin(), cams.end());
