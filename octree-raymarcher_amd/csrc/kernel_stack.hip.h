@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned n_iters = 0, n_tree_lanes = 0, n_twig_lanes = 0, n_world_lanes = 0;
     unsigned n_world_runs = 0, n_hit_runs = 0, n_refill = 0, n_tilegen = 0, n_fix = 0;
+    unsigned n_lane_twig = 0;
     unsigned n_lane_busy = 0;       // per lane: asm steps it entered a statement for as a marching lane; the wave's maximum is its critical path
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;   // block runs, lane-steps taken in it (this lane), rounds
     StepStats step_stats;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         const int fixed_steps = (n_busy >= SVO_STEP_LANES && __ballot(creepn > 0 || creepn <= -4 * SVO_CREEP_SERIOUS) == 0ull) ? SVO_STEP_EXTRA : 0;
         for (;;) {
 #ifdef SVO_STACK_TIMING
+        n_lane_twig += mode == M_TWIG ? (pass == 0 ? 1u + (unsigned)fixed_steps : (unsigned)SVO_DRAIN_STEPS) : 0u;        // ... of them started inside a brick
         n_lane_busy += (mode == M_TREE || mode == M_TWIG) ? (pass == 0 ? 1u + (unsigned)fixed_steps : (unsigned)SVO_DRAIN_STEPS) : 0u;     // steps of the coming statement this lane starts as a marching lane (an upper bound on its own steps)
         { const int nm = __popcll(__ballot(mode == M_TREE || mode == M_TWIG)); n_wsteps += nm > 0; n_lsteps += nm; if (more) { n_wsteps_b += nm > 0; n_lsteps_b += nm; n_hit_wait += __popcll(__ballot(mode == M_HIT)); n_dead_wait += __popcll(__ballot(mode == M_DONE)); n_world_wait += __popcll(__ballot(mode == M_WORLD)); n_twig_b += __popcll(__ballot(mode == M_TWIG)); } }
 #endif
@@ -777,12 +779,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     (void)n_creep_steps;
     unsigned busiest = n_lane_busy;
     for (int off = 32; off > 0; off >>= 1) busiest = max(busiest, (unsigned)__shfl_xor((int)busiest, off, 64));
+    unsigned busiest_twig = n_lane_busy == busiest ? n_lane_twig : 0u;          // the busiest lane's share inside bricks
+    for (int off = 32; off > 0; off >>= 1) busiest_twig = max(busiest_twig, (unsigned)__shfl_xor((int)busiest_twig, off, 64));
     if (lane == 0 && A.counters) {       // diagnostic build only: per-wave [start, end] in 10 ns ticks, iterations, rays
         uint4 c; c.x = (uint32_t)t_begin; c.y = (uint32_t)__builtin_amdgcn_s_memrealtime(); c.z = n_iters; c.w = total;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x] = c;
         uint4 e; e.x = n_world_runs | (n_hit_runs << 16); e.y = n_refill | (n_tilegen << 12) | (n_fix << 20); e.z = n_tree_lanes; e.w = n_twig_lanes | (n_world_lanes << 20);
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 1] = e;
-        uint4 f; f.x = n_creep_runs; f.y = busiest; f.z = n_creep_rounds; f.w = n_dbg;
+        uint4 f; f.x = n_creep_runs | (busiest_twig << 16); f.y = busiest; f.z = n_creep_rounds; f.w = n_dbg;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 2] = f;
         uint4 h; h.x = n_wsteps; h.y = n_lsteps; h.z = n_hit_wait; h.w = n_dead_wait;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 3] = h;

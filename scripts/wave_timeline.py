@@ -40,11 +40,12 @@ it = c[:, 2].astype(np.int64)
 print("iters  p50 %d p99 %d max %d   us/iter p50 %.2f" % (np.percentile(it, 50), np.percentile(it, 99), it.max(), np.median((en - st) / it)))
 late = np.argsort(en)[-8:]
 for i in late:
-    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d busiest-lane steps %d dbg ent %d go %d K>0 %d sure %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0], f[i, 2], f[i, 1], f[i, 3] & 255, (f[i, 3] >> 8) & 255, (f[i, 3] >> 16) & 255, f[i, 3] >> 24))
+    print("  wave end %.1f us start %.1f iters %d rays %d us/iter %.2f  creep runs %d rounds %d busiest-lane steps %d dbg ent %d go %d K>0 %d sure %d" % (en[i], st[i], it[i], c[i, 3], (en[i] - st[i]) / it[i], f[i, 0] & 0xFFFF, f[i, 2], f[i, 1], f[i, 3] & 255, (f[i, 3] >> 8) & 255, (f[i, 3] >> 16) & 255, f[i, 3] >> 24))
     print("      asm steps %d (%.1f marching lanes each; %.2f us per step over the wave's life), chunk-step runs %d, hit-block runs %d, refill rounds %d, tiles %d; step bodies after the tiles ran out: %d" % (
         per_wave_asm[i, 0], per_wave_asm[i, 1] / max(1, per_wave_asm[i, 0]), (en[i] - st[i]) / max(1, per_wave_asm[i, 0]), e[i, 0] & 0xFFFF, e[i, 0] >> 16, e[i, 1] & 0xFFF, (e[i, 1] >> 12) & 0xFF,
         int(h[i, 0]) - int(h[i, 4])))
 busy = f[:, 1].astype(np.int64)
+print("  ... of which started inside a brick (waves ending last): %s" % (f[late, 0] >> 16).tolist())
 print("busiest lane's asm steps per wave: p50 %d p90 %d p99 %d max %d; waves ending last: %s" % (*np.percentile(busy, [50, 90, 99, 100]), busy[late].tolist()))
 for t in (200, 400, 600, 800, 1000, 1200, 1500, 2000, 2500):
     print("t=%5d us running waves: %d" % (t, ((st <= t) & (en > t)).sum()))
@@ -57,7 +58,7 @@ print("block runs per iteration: world %.3f hit %.3f refill-rounds %.3f tilegen 
     (ex & 0xFFFF).sum() / its, (ex >> 16).sum() / its, (ey & 0xFFF).sum() / its, ((ey >> 12) & 0xFF).sum() / its, (ey >> 20).sum() / its))
 print("avg lanes per iteration: tree %.1f twig %.1f world %.1f" % (e[:, 2].astype(np.int64).sum() / its, (e[:, 3] & 0xFFFFF).astype(np.int64).sum() / its, (e[:, 3] >> 20).astype(np.int64).sum() / its))
 print("cycles per wave-iteration overall: %.0f" % (tot_wave_cycles / its))
-print("creep block: runs per iteration %.4f, rounds per run %.1f" % (f[:, 0].astype(np.int64).sum() / its, f[:, 2].astype(np.int64).sum() / max(1, f[:, 0].astype(np.int64).sum())))
+print("creep block: runs per iteration %.4f, rounds per run %.1f" % ((f[:, 0] & 0xFFFF).astype(np.int64).sum() / its, f[:, 2].astype(np.int64).sum() / max(1, (f[:, 0] & 0xFFFF).astype(np.int64).sum())))
 
 hs = h.astype(np.int64).sum(axis=0)
 print("step bodies executed %d (%.2f per iteration), marching lanes per step body %.2f of 64; wave cycles per step body %.0f" % (hs[0], hs[0] / its, hs[1] / max(1, hs[0]), tot_wave_cycles / max(1, hs[0])))
