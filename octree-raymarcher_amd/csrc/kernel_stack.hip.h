@@ -43,6 +43,10 @@
 //  * Lane state is kept small (re-basing points pw/pt and the node box are recomputed with the
 //    reference's own expressions instead of being held): 80 VGPRs, 6 waves per SIMD, no spill inside the pass loop.
 //  * The chunk table of worlds of up to 64 chunks sits in LDS: the chunk step waits for no global load.
+//  * Instantiations (round 4): BIG - 64-bit wide-tree and mask addresses for worlds beyond 4 GiB of wide nodes / 2^29 bricks, a
+//    128-chunk LDS table; GLSL - the march of shaders/Chunkmarch.glsl (svo_trace_params.semantics): guarded escape distance, LEAF
+//    hits at t, tnear > 0 at the world entry, no containment re-check.  The asm statement (step_asm_body.inc) and the creep block
+//    (creep_block.inc) are shared text; kernel_pool.hip.h is the over-subscribed experiment built on the same pieces.
 //
 // All float arithmetic that decides t is evaluated exactly as in the reference; only loads and
 // integer bookkeeping differ.  Divisions by powers of two (chunk edge, node edge) are written as
@@ -151,7 +155,7 @@ __device__ __forceinline__ uint32_t child_slot(int ux, int uy, int uz, int sh)
     return ((bz << 1) + by) * 2u + bx;
 }
 // node word at byte offset `boff` of the tree pool: scalar base + zero-extended 32-bit vector offset (one VGPR of address
-// instead of a 64-bit pointer per lane; the launch checks that the pool is smaller than 4 GiB)
+// instead of a 64-bit pointer per lane; pools of 4 GiB and more are marched by the BIG instantiation, which addresses with 64 bits)
 __device__ __forceinline__ uint32_t ld_node(const uint32_t *pool, uint32_t boff)
 {
     return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pool) + (size_t)boff);
