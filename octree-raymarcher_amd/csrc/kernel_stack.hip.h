@@ -95,7 +95,7 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 // steps per statement while the inner repeat lasts (the drain of a launch: the wave is alone on its SIMD, every instruction of the
 // loop control around the statement costs it ~5 cycles)
 #ifndef SVO_DRAIN_STEPS
-#define SVO_DRAIN_STEPS 4
+#define SVO_DRAIN_STEPS 8        // (round 4: 8 instead of 4 - one frame 1.62 - 1.63 ms against 1.655 - 1.659, the serialized 16-frame launch 8.79 against 8.91 - 8.99 ms; 16: the same as 8, 2: as 4)
 #endif
 #ifndef SVO_STEP_LANES
 #define SVO_STEP_LANES 8
