@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * POOL_WAVES, WAVES_PER_SIMD) void k_trace_pool(
     int nw_chunk = 1;
     const uint32_t lds_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)&stk[wave][0][lane];
     StepUniform SU;
-    SU.csize = csize; SU.eps = eps; SU.eps2 = 2.0f * eps; SU.cap_twig = A.cap_twig; SU.wide = A.wide; SU.mask = A.mask;
+    SU.csize = csize; SU.eps = eps; SU.eps2 = 2.0f * eps; SU.cap_twig = A.cap_twig; SU.wide = A.wide; SU.mask = A.mask; SU.descend_shift = MAXLV <= 10 ? SVO_DESCEND_SHIFT_SHALLOW : SVO_DESCEND_SHIFT_DEEP;
     int creepn = 0;
 #ifdef SVO_STACK_TIMING
     unsigned n_creep_runs = 0, n_creep_steps = 0, n_creep_rounds = 0, n_dbg = 0;       // (creep_block.inc counts into these in the timing build)

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     int nw_chunk = 1;
     const uint32_t lds_lane = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)&stk[0][lane];
     StepUniform SU;
-    SU.csize = csize; SU.eps = eps; SU.eps2 = 2.0f * eps; SU.cap_twig = A.cap_twig; SU.wide = A.wide; SU.mask = A.mask;
+    SU.csize = csize; SU.eps = eps; SU.eps2 = 2.0f * eps; SU.cap_twig = A.cap_twig; SU.wide = A.wide; SU.mask = A.mask; SU.descend_shift = MAXLV <= 10 ? SVO_DESCEND_SHIFT_SHALLOW : SVO_DESCEND_SHIFT_DEEP;
 #endif
     // creeping rays: |creepn| = consecutive advances of this ray by less than 2 EPS (kept across level changes: a ray pinned
     // on a chunk face creeps at every level); > 0 only while the cell located last is known to be empty (creep block armed)

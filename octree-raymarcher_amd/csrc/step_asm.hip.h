@@ -40,8 +40,14 @@
 #pragma once
 #include "march.hip.h"
 
-#ifndef SVO_DESCEND_SHIFT
-#define SVO_DESCEND_SHIFT 2      // a wide level is taken inside the step when more than 1 / 2^this of the wave's tree lanes stand at a BRANCH entry
+// A wide level is taken inside the step when more than 1 / 2^shift of the wave's tree lanes stand at a BRANCH entry (StepUniform::descend_shift).
+// Round 4 re-swept it: a HALF (shift 1) instead of a quarter is +1.2 % on C3, +3 % on C2, nothing on C4 - and -2.6 % on C5, whose fresh rays
+// descend seven wide levels from the root: shallow trees (<= 10 branch levels) use 1, deeper ones 2 (shift 3: -3 % on C3; 0 = never: C3 +0.2 %, C5 -7 %).
+#ifndef SVO_DESCEND_SHIFT_SHALLOW
+#define SVO_DESCEND_SHIFT_SHALLOW 1
+#endif
+#ifndef SVO_DESCEND_SHIFT_DEEP
+#define SVO_DESCEND_SHIFT_DEEP 2
 #endif
 #ifdef SVO_STACK_TIMING
 #define SVO_STAT(text) text
@@ -60,6 +66,7 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
     int cap_twig;
     const uint32_t *wide;
     const uint64_t *mask;
+    int descend_shift;
 };
 
 // The statement's variants (step_asm_body.inc is included once per variant):
