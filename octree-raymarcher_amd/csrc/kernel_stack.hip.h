@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         if (run_world && mode == M_WORLD) {
             if (cw < 0) {                               // left its chunk in the step: t += escape(chunk box) + EPS, src/Traverse.cpp:164-168
                 cw &= ~CW_ESCAPE_PENDING;
-                tw += guarded(escape(O, g, clo, clo + csize), A.guard_eps) + eps;
+                if constexpr (GLSL) tw += guarded(escape(O, g, clo, clo + csize), eps) + eps;       // (the guard's threshold IS the march's EPS, Chunkmarch.glsl:113)
+                else tw += escape(O, g, clo, clo + csize) + eps;
             }
             bool miss = cw >= A.cap_chunk;
             if (!miss) {
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                     bool contained = inside(p, clo, clo + csize);
                     // src/Traverse.cpp:154-155: a position outside the box of the chunk found for it ends the ray.  The shader has no
                     // such check (shaders/Chunkmarch.glsl:297-330): its treemarch fails at once, and rootmarch steps on out of that box
-                    if (GLSL && !contained) tw += guarded(escape(p, g, clo, clo + csize), A.guard_eps) + eps;     // (stays M_WORLD; cw counts it)
+                    if (GLSL && !contained) tw += guarded(escape(p, g, clo, clo + csize), eps) + eps;     // (stays M_WORLD; cw counts it)
                     else miss = !contained;
                     if (contained) {                    // treemarch(p, beta, chunk): a = p, t = 0 (src/Traverse.cpp:158,78)
                         if constexpr (BIG) wide_b = (unsigned long long)(size_t)A.wide + ((unsigned long long)ch_wide << 8);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
             if (what == S_ADVANCE || what == S_ENTER) {
                 const V3 E_lo = mk(Blo.x + (float)(ux & ~low) * res, Blo.y + (float)(uy & ~low) * res, Blo.z + (float)(uz & ~low) * res);
                 const float E_size = res * (float)(low + 1);
-                const float e = guarded(escape(p, g, E_lo, E_lo + E_size), A.guard_eps) + eps;
+                const float e = (GLSL ? guarded(escape(p, g, E_lo, E_lo + E_size), eps) : escape(p, g, E_lo, E_lo + E_size)) + eps;
                 if (what == S_ADVANCE) {
                     t += e;
                     creepn = e < 2.0f * eps ? crept + 1 : 0;        // pinned on a lattice plane: see the creep block
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
                 }
             }
             if (what == S_HIT_LEAF) {
-                tw = tw + (t - A.leaf_back);                        // src/Traverse.cpp:93,160 (t - EPS); shaders/Chunkmarch.glsl:266 (t)
+                tw = tw + (GLSL ? t : t - eps);                     // src/Traverse.cpp:93,160 (t - EPS); shaders/Chunkmarch.glsl:266 (t)
                 cnt = (int)SVO_CELL_NONE;
                 mode = M_HIT;
             }
