@@ -4,7 +4,7 @@ line of their call site where the .loc carries it, else to their own file.  Runs
 import collections, re, sys, os
 S = sys.argv[1]
 lines = open(S).read().split('\n')
-name = '_ZN3svo13k_trace_stackILi10ELi8ELi6ELb0EEEvNS_9TraceArgsE'
+name = '_ZN3svo13k_trace_stackILi10ELi8ELi6ELb0ELb0EEEvNS_9TraceArgsE'
 start = [i for i, l in enumerate(lines) if l.startswith(name + ':')][0]
 end = [i for i in range(start, len(lines)) if 's_endpgm' in lines[i]][0]
 files = {}
@@ -16,7 +16,7 @@ def find(text):
     return [i + 1 for i, l in enumerate(src) if text in l][0]
 marks = [("prologue", 1), ("refill", find("==== refill retired lanes")), ("votes + guard", find("==== votes: which of the rare blocks")),
          ("chunk step", find("---- chunk step: src/Traverse.cpp:142-156")), ("step (asm call + loop control)", find("---- one step of the current level")),
-         ("creep block", find("---- creep block.")), ("hit blocks", find("---- hits.  A shadow ray only sets a flag")), ("epilogue", find("unsigned total = rays_marched;"))]
+         ("creep block", find("#include \"creep_block.inc\"")), ("hit blocks", find("---- hits.  A shadow ray only sets a flag")), ("epilogue", find("unsigned total = rays_marched;"))]
 def region(ln):
     r = marks[0][0]
     for nm, first in marks:
@@ -36,5 +36,5 @@ for l in lines[start:end]:
     cls = 'valu' if op.startswith('v_') else 'salu' if op.startswith('s_') else 'mem' if op.startswith(('global_', 'ds_', 'scratch_', 'buffer_', 'flat_')) else 'other'
     tot[cur] += 1; kinds[cur][cls] += 1
 for k, v in sorted(tot.items(), key=lambda x: -x[1]):
-    print(f"{v:6d}  {k:40s} {dict(kinds[k])}")
+    print(f"{v:6d}  {str(k):40s} {dict(kinds[k])}")
 print("total", sum(tot.values()))
