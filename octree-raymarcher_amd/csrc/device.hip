@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -172,8 +173,9 @@ int release_device(svo_world &w)
     }
     w.work_event.clear();
     w.d_chunks = nullptr; w.d_tree = nullptr; w.d_twig = nullptr; w.d_mask = nullptr; w.d_bmat = nullptr; w.d_work = nullptr;
-    w.d_wide = nullptr; w.d_wbase = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0;
+    w.d_wide = nullptr; w.d_wbase = nullptr; w.d_wchunks = nullptr; w.d_wscratch = nullptr; w.wscratch_words = 0; w.wscan_words = 0;
     w.d_sort = nullptr; w.sort_bytes = 0; w.sort_event = nullptr;
+    if (w.h_wide_tail) { (void)hipHostFree(w.h_wide_tail); w.h_wide_tail = nullptr; }
     w.device = -1;
     w.table.clear(); w.tree_slot.clear(); w.twig_slot.clear(); w.wtable.clear(); w.wide_slot.clear();
     w.tree_pool_len = w.twig_pool_len = w.tree_pool_cap = w.twig_pool_cap = 0;
@@ -349,6 +351,7 @@ int fetch_pools(svo_world &w, int chunk)
 // The wide tree of chunk `chunk` (wide_tree.hip.h) from its node words in the tree pool, level by level, into
 // wide_dst / wbase_dst (room for slot_cap wide nodes); *count = wide nodes written.  The per-entry reference indices that link
 // one level to the next live in the builder's scratch.
+constexpr int WIDE_SLOT_FULL = 100;     // expand_wide_chunk: the chunk's wide tree does not fit slot_cap (not an svo_status: never leaves this file)
 static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *wide_dst, uint32_t *wbase_dst, uint64_t slot_cap, uint64_t *count_out)
 {
     const ChunkPools &c = w.chunks[(size_t)chunk];
@@ -360,12 +363,14 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
     uint32_t *front = w.d_wscratch, *next = front + B, *flag = next + B, *rank = flag + 64 * B, *wref_dst = rank + 64 * B;
     const uint32_t *tree = w.d_tree + e.tree_off;
     HIP_TRY(hipMemsetAsync(front, 0, sizeof(uint32_t), s));             // the top wide node expands reference node 0
+    if (!w.h_wide_tail && hipHostMalloc((void **)&w.h_wide_tail, 2 * sizeof(uint32_t)) != hipSuccess) { set_error("wide tree: hipHostMalloc failed"); return SVO_ERR_OUT_OF_MEMORY; }
     uint32_t count = 1, first = 0;
-    void *tmp = nullptr;
-    size_t tmp_bytes = 0;
+    // the scan's own scratch lies behind the builder's (reserve_wide_scratch sized it for the largest level): no hipMalloc / hipFree per chunk
+    void *tmp = w.d_wscratch + (w.wscratch_words - w.wscan_words);
+    const size_t tmp_bytes = w.wscan_words * sizeof(uint32_t);
     int rc = SVO_OK;
     for (uint32_t k = 0; k < nw && count > 0; ++k) {
-        if ((uint64_t)first + count > slot_cap) { set_error("wide tree: slot overflow"); rc = SVO_ERR_MALFORMED_TREE; break; }
+        if ((uint64_t)first + count > slot_cap) { rc = WIDE_SLOT_FULL; break; }      // (the callers turn this into a larger slot, or into an error)
         const uint32_t n = count * 64u;
         hipLaunchKernelGGL(k_wide_expand, dim3((n + 255) / 256), dim3(256), 0, s, tree, front, count, first,
                            k == 0 ? pad : 0, 2u * k + 1u - (uint32_t)pad, wide_dst, wref_dst, wbase_dst, flag);
@@ -373,12 +378,8 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
         if (k + 1 == nw) { first += count; count = 0; break; }         // grandchildren of the last wide level are never BRANCH
         size_t bytes = 0;
         if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag, rank, (int)n, s) != hipSuccess) { rc = SVO_ERR_HIP; break; }
-        if (bytes > tmp_bytes) {
-            if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); tmp = nullptr; }
-            if (hipMalloc(&tmp, bytes + 256) != hipSuccess) { set_error("wide tree: hipMalloc failed"); rc = SVO_ERR_OUT_OF_MEMORY; break; }
-            tmp_bytes = bytes + 256;
-        }
-        uint32_t tail[2] = { 0, 0 };
+        if (bytes > tmp_bytes) { set_error("wide tree: the scan asks for more scratch than was reserved"); rc = SVO_ERR_HIP; break; }
+        uint32_t *tail = w.h_wide_tail;                                 // pinned: a pageable destination stages every 4-byte copy
         if (hipcub::DeviceScan::ExclusiveSum(tmp, bytes, flag, rank, (int)n, s) != hipSuccess ||
             hipMemcpyAsync(&tail[0], rank + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipMemcpyAsync(&tail[1], flag + (n - 1), 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -393,7 +394,6 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
         std::swap(front, next);
     }
     (void)hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
     if (rc == SVO_OK && count_out) *count_out = first;
     return rc;
 }
@@ -402,11 +402,17 @@ static int expand_wide_chunk(svo_world &w, int chunk, hipStream_t s, uint32_t *w
 static int reserve_wide_scratch(svo_world &w, uint64_t largest_tree)
 {
     const uint64_t B = largest_tree / 8 + 1;
-    const uint64_t need = 2 * B + 2 * 64 * B + 2 * 64 * B + WIDE_BASE_WORDS * B + 1024;        // fronts, flags + ranks, entry references + a throw-away tree, its bases
-    if (need <= w.wscratch_words) return SVO_OK;
-    if (w.d_wscratch) { (void)hipDeviceSynchronize(); pool_free(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; }
+    size_t scan_bytes = 0;
+    uint32_t *nul = nullptr;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, nul, nul, (int)(64 * B), (hipStream_t)nullptr) != hipSuccess) { set_error("wide tree: scan size query failed"); return SVO_ERR_HIP; }
+    const uint64_t scan_words = (scan_bytes + 3) / 4 + 64;
+    // fronts, flags + ranks, entry references + a throw-away tree, its bases; the scan's scratch (kept 256-byte aligned: everything before it is a multiple of 64 words)
+    const uint64_t body = ((2 * B + 2 * 64 * B + 2 * 64 * B + WIDE_BASE_WORDS * B + 1024 + 63) / 64) * 64;
+    const uint64_t need = body + scan_words;
+    if (scan_words <= w.wscan_words && body <= w.wscratch_words - w.wscan_words) return SVO_OK;
+    if (w.d_wscratch) { (void)hipDeviceSynchronize(); pool_free(w.d_wscratch); w.d_wscratch = nullptr; w.wscratch_words = 0; w.wscan_words = 0; }
     if (pool_malloc((void **)&w.d_wscratch, need * sizeof(uint32_t), w.device) != hipSuccess) { set_error("wide tree: hipMalloc of the builder scratch failed"); return SVO_ERR_OUT_OF_MEMORY; }
-    w.wscratch_words = need;
+    w.wscratch_words = need; w.wscan_words = scan_words;
     return SVO_OK;
 }
 static bool wide_fits(const svo_world &w, int chunk)
@@ -432,7 +438,7 @@ static void drop_wide_scratch(svo_world &w, bool failed = true)
     // the next one; everybody else gets the ~1 GB back
     if (!failed && w.builder_ctx) return;
     if (w.d_wscratch) { (void)hipDeviceSynchronize(); pool_free(w.d_wscratch); w.d_wscratch = nullptr; }
-    w.wscratch_words = 0;
+    w.wscratch_words = 0; w.wscan_words = 0;
 }
 // test hook (the `hooks` variant of the Makefile only; the shipped library reads no such variable): SVO_TEST_FAIL_WIDE=1 makes
 // the next wide-tree build fail as an allocation failure would
@@ -464,30 +470,67 @@ int build_wide_all(svo_world &w, void *stream)
     if (rc != SVO_OK) { drop_wide_scratch(w); return rc; }
     const uint64_t Bmax = largest / 8 + 1;
     uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 3 * 64 * Bmax, *tmp_wbase = tmp_wide + 64 * Bmax;
+    // One pass (until round 4 every chunk was expanded twice: a count pass into scratch sized the pool, a build pass filled it): the
+    // largest chunk is counted, the pool is sized from its wide nodes per BRANCH node (+ 35 %) for all chunks, and every chunk is built in
+    // place behind the previous one's slot (= its wide nodes + 1/8 + 16); a pool that turns out too small is grown (x 1.5, copied):
+    // entries hold wide-node indices relative to their chunk's top node, so a built chunk can move.
+    uint64_t count0 = 0;
+    size_t sample = 0;                                                          // the chunk with the most nodes stands for all of them
+    for (size_t i = 0; i < n; ++i) if (w.chunks[i].tree_count() > w.chunks[sample].tree_count()) sample = i;
+    if ((rc = expand_wide_chunk(w, (int)sample, s, tmp_wide, tmp_wbase, Bmax, &count0)) != SVO_OK) {
+        if (rc == WIDE_SLOT_FULL) { set_error("wide tree: more wide nodes than BRANCH nodes"); rc = SVO_ERR_MALFORMED_TREE; }
+        drop_wide_scratch(w); return rc;
+    }
+    uint64_t branches = 0;
+    for (size_t i = 0; i < n; ++i) branches += w.chunks[i].tree_count() / 8 + 1;
+    const double per_branch = (double)count0 / (double)(w.chunks[sample].tree_count() / 8 + 1);
+    uint64_t cap = (uint64_t)((double)branches * per_branch * 1.35) + 32 * n + 64;
+    cap = std::max<uint64_t>(cap, count0 + count0 / 8 + 16 + 64);
+    auto alloc_pool = [&](uint64_t nodes, uint32_t **wide, uint32_t **wbase) {
+        *wide = *wbase = nullptr;
+        if (nodes >= (1ull << 32)) return false;
+        if (pool_malloc((void **)wide, nodes * 64 * sizeof(uint32_t), w.device) != hipSuccess) return false;
+        if (pool_malloc((void **)wbase, nodes * WIDE_BASE_WORDS * sizeof(uint32_t), w.device) != hipSuccess) { pool_free(*wide); *wide = nullptr; return false; }
+        return true;
+    };
+    if (cap >= (1ull << 32)) { drop_wide_scratch(w); return SVO_OK; }         // wide node indices are 32-bit (1 TiB of wide nodes): literal kernel
+    if (!alloc_pool(cap, &w.d_wide, &w.d_wbase)) {
+        drop_wide(w); drop_wide_scratch(w);
+        set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY;
+    }
     uint64_t cur = 0, used = 0;
-    for (size_t i = 0; i < n; ++i) {
+    auto grow_pool = [&](uint64_t at_least) -> int {
+        uint64_t bigger = std::max<uint64_t>(cap + cap / 2, at_least + at_least / 16 + 64);
+        if (bigger >= (1ull << 32)) return 1;                                   // literal kernel
+        uint32_t *nw = nullptr, *nb = nullptr;
+        if (!alloc_pool(bigger, &nw, &nb)) return SVO_ERR_OUT_OF_MEMORY;
+        if (hipMemcpyAsync(nw, w.d_wide, cur * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(nb, w.d_wbase, cur * WIDE_BASE_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { pool_free(nw); pool_free(nb); return SVO_ERR_HIP; }
+        pool_free(w.d_wide); pool_free(w.d_wbase);
+        w.d_wide = nw; w.d_wbase = nb; cap = bigger;
+        return SVO_OK;
+    };
+    for (size_t i = 0; i < n; ) {
         uint64_t count = 0;
-        if ((rc = expand_wide_chunk(w, (int)i, s, tmp_wide, tmp_wbase, Bmax, &count)) != SVO_OK) { drop_wide_scratch(w); return rc; }
+        rc = expand_wide_chunk(w, (int)i, s, w.d_wide + cur * 64, w.d_wbase + cur * WIDE_BASE_WORDS, cap - cur, &count);
+        const uint64_t slot = count + count / 8 + 16;
+        if (rc == WIDE_SLOT_FULL || (rc == SVO_OK && cur + slot > cap)) {        // (grow, then this chunk again)
+            const uint64_t bound = w.chunks[i].tree_count() / 8 + 1;
+            const int g = grow_pool(cur + (rc == SVO_OK ? slot : std::min<uint64_t>(bound, 2 * (cap - cur) + 1024)));
+            if (g == 1) { drop_wide(w); drop_wide_scratch(w); return SVO_OK; }
+            if (g != SVO_OK) { drop_wide(w); drop_wide_scratch(w); set_error("wide tree: growing the pool failed"); return g; }
+            continue;
+        }
+        if (rc != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
         const DevChunk &e = w.table[i];
         DevWide &v = w.wtable[i];
         v.bmin[0] = e.bmin[0]; v.bmin[1] = e.bmin[1]; v.bmin[2] = e.bmin[2];
         v.levels = e.levels; v.wide_off = (uint32_t)cur; v._pad = 0; v.twig_off = e.twig_off;
-        w.wide_slot[i] = count + count / 8 + 16;
-        cur += w.wide_slot[i];
+        w.wide_slot[i] = slot;
+        cur += slot;
         used += count;
-    }
-    const uint64_t cap = cur + cur / 16 + 64;
-    if (cap >= (1ull << 32)) { drop_wide_scratch(w); return SVO_OK; }         // wide node indices are 32-bit (1 TiB of wide nodes): literal kernel
-    if (pool_malloc((void **)&w.d_wide, cap * 64 * sizeof(uint32_t), w.device) != hipSuccess ||
-        pool_malloc((void **)&w.d_wbase, cap * WIDE_BASE_WORDS * sizeof(uint32_t), w.device) != hipSuccess) {
-        drop_wide(w); drop_wide_scratch(w);
-        set_error("wide tree: hipMalloc of the pool failed"); return SVO_ERR_OUT_OF_MEMORY;
-    }
-    for (size_t i = 0; i < n; ++i) {
-        const DevWide &v = w.wtable[i];
-        if ((rc = expand_wide_chunk(w, (int)i, s, w.d_wide + (uint64_t)v.wide_off * 64, w.d_wbase + (uint64_t)v.wide_off * WIDE_BASE_WORDS, w.wide_slot[i], nullptr)) != SVO_OK) {
-            drop_wide(w); drop_wide_scratch(w); return rc;
-        }
+        ++i;
     }
     if (hipMemcpy(w.d_wchunks, w.wtable.data(), n * sizeof(DevWide), hipMemcpyHostToDevice) != hipSuccess) {
         drop_wide(w); drop_wide_scratch(w); set_error("wide tree: chunk table copy failed"); return SVO_ERR_HIP;
@@ -516,7 +559,10 @@ int rebuild_wide_chunk(svo_world &w, int chunk, void *stream)
     const uint64_t Bmax = c.tree_count() / 8 + 1;
     uint32_t *tmp_wide = w.d_wscratch + 2 * Bmax + 3 * 64 * Bmax, *tmp_wbase = tmp_wide + 64 * Bmax;
     uint64_t count = 0;
-    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wbase, Bmax, &count)) != SVO_OK) { drop_wide(w); drop_wide_scratch(w); return rc; }
+    if ((rc = expand_wide_chunk(w, chunk, s, tmp_wide, tmp_wbase, Bmax, &count)) != SVO_OK) {
+        if (rc == WIDE_SLOT_FULL) { set_error("wide tree: more wide nodes than BRANCH nodes"); rc = SVO_ERR_MALFORMED_TREE; }
+        drop_wide(w); drop_wide_scratch(w); return rc;
+    }
     DevWide &v = w.wtable[(size_t)chunk];
     const DevChunk &e = w.table[(size_t)chunk];
     if (count > w.wide_slot[(size_t)chunk]) {

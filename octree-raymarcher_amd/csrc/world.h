@@ -31,7 +31,8 @@ struct svo_world {
     std::vector<uint64_t> wide_slot;              // capacity of each chunk's wide slot (wide nodes)
     uint64_t wide_pool_len = 0, wide_pool_cap = 0, wide_nodes_used = 0;
     uint32_t *d_wscratch = nullptr;               // builder scratch: fronts, flags, ranks
-    uint64_t wscratch_words = 0;
+    uint32_t *h_wide_tail = nullptr;              // pinned: the wide builder's per-level read-back
+    uint64_t wscratch_words = 0, wscan_words = 0;  // its size; the tail of it that is the scan's own scratch
     void *builder_ctx = nullptr;                  // builder.hip: working buffers svo_world_shift / svo_world_edit_box keep between calls
     void *d_sort = nullptr;                       // svo_tile_order scratch
     size_t sort_bytes = 0;
