@@ -486,6 +486,10 @@ int build_wide_all(svo_world &w, void *stream)
     const double per_branch = (double)count0 / (double)(w.chunks[sample].tree_count() / 8 + 1);
     uint64_t cap = (uint64_t)((double)branches * per_branch * 1.35) + 32 * n + 64;
     cap = std::max<uint64_t>(cap, count0 + count0 / 8 + 16 + 64);
+#ifdef SVO_TEST_HOOKS
+    // (the `hooks` variant only) SVO_TEST_WIDE_ESTIMATE=<factor> scales the estimate, so that the tests reach the growth path
+    if (const char *e = std::getenv("SVO_TEST_WIDE_ESTIMATE")) cap = std::max<uint64_t>(64, (uint64_t)((double)cap * std::atof(e)));
+#endif
     auto alloc_pool = [&](uint64_t nodes, uint32_t **wide, uint32_t **wbase) {
         *wide = *wbase = nullptr;
         if (nodes >= (1ull << 32)) return false;

@@ -177,6 +177,24 @@ def hooks(svo, ob):
     for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
         assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"shifted again/{k}")
     W.destroy()
+    # (d) the wide pool is sized from an estimate (wide nodes per BRANCH node of the largest chunk) and grown when that was too little:
+    # with the estimate cut to 2 % the pool is grown - and the chunks built so far moved - several times over
+    os.environ["SVO_TEST_WIDE_ESTIMATE"] = "0.02"
+    W = svo.World.generate(3, 1, 2, 128, 8, build_device=0, chunkcoordmin=(-1, 0, 0))
+    del os.environ["SVO_TEST_WIDE_ESTIMATE"]
+    assert W.info.wide_nodes > 0
+    O = ob.OracleWorld.from_chunks([W.chunk(i) for i in range(6)], 3, 1, 2, 128, (-1, 0, 0))
+    o, d = random_rays(rng, 20000, (-128, 0, 0), (256, 128, 256))
+    want = O.trace_rays(o, d, params=ob.make_params(shadow=True), threads=8)
+    assert (want["flags"] & 1).sum() > 3000
+    for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"grown wide pool/{k}")
+    grown = W.info.wide_pool_bytes
+    W.destroy()
+    W = svo.World.generate(3, 1, 2, 128, 8, build_device=0, chunkcoordmin=(-1, 0, 0))
+    assert W.info.wide_nodes > 0 and abs(W.info.wide_pool_bytes - grown) < grown     # (the estimate alone: the same order of size)
+    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_STACK), want, "estimated wide pool")
+    W.destroy()
     print("hooks: failed wide rebuilds behind update / edit_box / shift leave the change applied and the literal kernel marching; the next one recovers")
 
 
