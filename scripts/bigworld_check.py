@@ -26,6 +26,12 @@ def throughput(W, gw, gd, frames=16, launches=6):
         eye = (gw * 64.0 + np.cos(a) * gw * 70.0 + 0.37, 150.0 + 10.0 * np.sin(3 * a), gd * 64.0 + np.sin(a) * gd * 70.0 + 0.41)
         fwd = (gw * 64.0 - eye[0], -110.0, gd * 64.0 - eye[2])
         cams.append(svo.make_camera(eye, fwd, (0, 1, 0), 60.0, w, h))
+    # what a ray costs on THIS world: reference steps (tree steps + brick cells tested, the literal kernel's counters) per ray on four of the cameras
+    steps = rays4 = 0
+    for cam in cams[::max(1, frames // 4)][:4]:
+        g, c = W.draw(cam, shadow=True, kernel=svo.KERNEL_LITERAL, counters=True)
+        steps += int(c[..., 3].astype(np.int64).sum() + c[..., 1].astype(np.int64).sum()); rays4 += W.last_ray_count()
+    per_ray = steps / max(1, rays4)
     out = svo.DeviceBuffer(frames * w * h * 32)
     prm = svo.trace_params(shadow=True, kernel=svo.KERNEL_STACK)
     W.trace_frames(cams, prm, (0, 0, w, h), out.ptr); svo.lib.svo_stream_synchronize(None)     # warm
@@ -36,7 +42,7 @@ def throughput(W, gw, gd, frames=16, launches=6):
     svo.lib.svo_stream_synchronize(None)
     dt = time.time() - t
     out.free()
-    return rays * launches / dt / 1e6, dt / launches * 1e3, rays
+    return rays * launches / dt / 1e6, dt / launches * 1e3, rays, per_ray
 
 
 t = time.time(); W = svo.World.generate(gw, 1, gd, 128, depth, build_device=0 if on_device else None); tg = time.time() - t
@@ -58,12 +64,14 @@ assert c.tobytes() == a.tobytes()
 print(f"1080p frame: stack == literal == auto, {int((a['flags'] & 1).sum())} hits (draw incl. read-back: stack {ts*1e3:.0f} ms, literal {tl*1e3:.0f} ms)", flush=True)
 # 2. throughput next to the C3 world's
 big = throughput(W, gw, gd)
-print(f"stack kernel on this world: {big[0]:.0f} Mrays/s ({big[1]:.2f} ms per 16-frame launch, {big[2]/16e6:.2f} M rays per frame)", flush=True)
+print(f"stack kernel on this world: {big[0]:.0f} Mrays/s ({big[1]:.2f} ms per 16-frame launch, {big[2]/16e6:.2f} M rays per frame, {big[3]:.1f} reference steps per ray "
+      f"= {big[0]*big[3]/1e3:.1f} G reference steps/s)", flush=True)
 if not (len(sys.argv) > 4 and sys.argv[4] == "noc3"):
     C3 = svo.World.generate(4, 1, 4, 128, depth, build_device=0)
     c3 = throughput(C3, 4, 4)
     C3.destroy()
-    print(f"stack kernel on the C3 world (4x1x4): {c3[0]:.0f} Mrays/s ({c3[1]:.2f} ms per launch, {c3[2]/16e6:.2f} M rays per frame); ratio big / C3 = {big[0]/c3[0]:.3f}", flush=True)
+    print(f"stack kernel on the C3 world (4x1x4): {c3[0]:.0f} Mrays/s ({c3[1]:.2f} ms per launch, {c3[2]/16e6:.2f} M rays per frame, {c3[3]:.1f} reference steps per ray "
+          f"= {c3[0]*c3[3]/1e3:.1f} G reference steps/s); ratio big / C3 = {big[0]/c3[0]:.3f} in rays, {big[0]*big[3]/(c3[0]*c3[3]):.3f} in reference steps", flush=True)
 # 3. against the CPU oracle over the same arrays
 n = gw * gd
 t = time.time()
