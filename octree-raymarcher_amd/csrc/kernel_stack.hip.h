@@ -277,7 +277,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
     const int lane = threadIdx.x;
     const bool want_cost = A.tile_cost != nullptr;      // (one SGPR held; the blocks below must not re-read the kernel arguments for a feature that is off)
     const int n_chunks = A.dimw * A.dimh * A.dimd;
+#ifdef SVO_NO_LDS_CHUNK_TAB      // experiment (scripts/build_variants.sh): what the chunk table costs once it has left LDS (worlds of more than CHUNK_TAB chunks)
+    const bool chunks_in_lds = false;
+#else
     const bool chunks_in_lds = n_chunks <= CHUNK_TAB;
+#endif
     if (chunks_in_lds)
         for (int i = lane; i < n_chunks; i += 64) {
             const DevWide ch = A.wchunks[i];

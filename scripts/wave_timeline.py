@@ -6,8 +6,13 @@ sys.path.insert(0, ROOT)
 svo = importlib.import_module("octree-raymarcher_amd")
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # frames per launch
-W = svo.World.generate(4, 1, 4, 128, depth); W.upload(0)
-cam = svo.default_camera(4, 4, 128, 1920, 1080)
+G = int(os.environ.get("SVO_WT_GRID", "4"))              # GxG chunks
+W = svo.World.generate(G, 1, G, 128, depth, build_device=0)
+cam = svo.default_camera(G, G, 128, 1920, 1080)
+if os.environ.get("SVO_WT_ORBIT"):                      # camera f of the 16-camera orbit of scripts/bigworld_check.py / slow_world_probe.py
+    a = 2.0 * np.pi * int(os.environ["SVO_WT_ORBIT"]) / 16
+    eye = (G * 64.0 + np.cos(a) * G * 70.0 + 0.37, 150.0 + 10.0 * np.sin(3 * a), G * 64.0 + np.sin(a) * G * 70.0 + 0.41)
+    cam = svo.make_camera(eye, (G * 64.0 - eye[0], -110.0, G * 64.0 - eye[2]), (0, 1, 0), 60.0, 1920, 1080)
 if os.environ.get("SVO_BENCH_EYE_DX"):
     cam.eye[0] += float(os.environ["SVO_BENCH_EYE_DX"])
 if os.environ.get("SVO_PATH_CAM"):                      # camera k of bench.py's path
