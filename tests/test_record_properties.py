@@ -123,25 +123,30 @@ def test_oracle_records_mean_what_they_say(oracle):
     assert check_records(rec, o, d, chunks, True, 0, eps=1.0 / 4096.0, leaf_backoff=False, what="oracle, GLSL twin") > 5000
 
 
+def pixel_rays(cam):
+    """Origins and directions of a camera's pixels: the product's own camera formula in float32, vectorised (include/svo.h svo_camera) - a wrong
+    ray would put the hit positions outside their voxels."""
+    w, h = cam.width, cam.height
+    fx = (np.arange(w, dtype=np.float32) + np.float32(0.5)); fy = (np.arange(h, dtype=np.float32) + np.float32(0.5))
+    u = ((fx / np.float32(w)) * np.float32(2.0) - np.float32(1.0)) * np.float32(cam.tan_half_x)
+    v = (np.float32(1.0) - (fy / np.float32(h)) * np.float32(2.0)) * np.float32(cam.tan_half_y)
+    fwd, right, up = (np.array(list(x), np.float32) for x in (cam.forward, cam.right, cam.up))
+    dirs = (fwd[None, None, :] + right[None, None, :] * u[None, :, None]) + up[None, None, :] * v[:, None, None]
+    dirs = dirs * (np.float32(1.0) / np.sqrt((dirs * dirs).sum(axis=2, dtype=np.float32)))[:, :, None]
+    dirs = dirs.reshape(-1, 3).astype(np.float32)
+    return np.broadcast_to(np.array(list(cam.eye), np.float32), dirs.shape), dirs
+
+
 @pytest.mark.gpu
 def test_full_size_frames_mean_what_they_say(svo, oracle):
     """BASELINE configs[2] at full size: every one of the ~1.1 M hit records of the 1920x1080 C3 frame (both kernels, CPU semantics and
-    the GLSL twin's) against the world's pools - node words, materials, voxel boxes from node indices, chunk boxes; and C2's frame."""
+    the GLSL twin's) against the world's pools - node words, materials, voxel boxes from node indices, chunk boxes; C2's frame; and C5's (depth 16, sparse)."""
     import bench
     for workload, (gw, gd, depth) in (("c3_1080p_depth12_4x1x4_shadow", (4, 4, 12)), ("c2_1080p_depth10_1chunk", (1, 1, 10))):
         W = svo.World.generate(gw, 1, gd, 128, depth, build_device=0)
         chunks = [W.chunk(i, copy=False) for i in range(gw * gd)]
         cam = bench.camera_path(svo, workload, gw, gd, 1920, 1080)[7]
-        # pixel rays: the product's own camera formula in float32, vectorised (include/svo.h svo_camera) - a wrong ray would put the hit positions outside their voxels
-        w, h = cam.width, cam.height
-        fx = (np.arange(w, dtype=np.float32) + np.float32(0.5)); fy = (np.arange(h, dtype=np.float32) + np.float32(0.5))
-        u = ((fx / np.float32(w)) * np.float32(2.0) - np.float32(1.0)) * np.float32(cam.tan_half_x)
-        v = (np.float32(1.0) - (fy / np.float32(h)) * np.float32(2.0)) * np.float32(cam.tan_half_y)
-        fwd, right, up = (np.array(list(x), np.float32) for x in (cam.forward, cam.right, cam.up))
-        dirs = (fwd[None, None, :] + right[None, None, :] * u[None, :, None]) + up[None, None, :] * v[:, None, None]
-        dirs = dirs * (np.float32(1.0) / np.sqrt((dirs * dirs).sum(axis=2, dtype=np.float32)))[:, :, None]
-        dirs = dirs.reshape(-1, 3).astype(np.float32)
-        origins = np.broadcast_to(np.array(list(cam.eye), np.float32), dirs.shape)
+        origins, dirs = pixel_rays(cam)
         shadow = "shadow" in workload
         for kernel in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
             for sem, eps, back in ((0, EPS, True), (1, 1.0 / 4096.0, False)):
@@ -149,3 +154,15 @@ def test_full_size_frames_mean_what_they_say(svo, oracle):
                 n = check_records(rec, origins, dirs, chunks, shadow, 0, eps=eps, leaf_backoff=back, what=f"{workload} kernel {kernel} semantics {sem}")
                 assert n > 300000, (workload, n)
         W.destroy()
+    # BASELINE configs[4]: one depth-16 chunk, refined to full depth only in a band (bricks under nodes of level 8 and of level 14 in one tree)
+    scene = svo.c5_scene()
+    W = svo.World.generate(1, 1, 1, 128, 16, **scene["generate"])
+    chunks = [W.chunk(0, copy=False)]
+    W.upload(0)
+    cam = scene["camera"](1920, 1080)
+    origins, dirs = pixel_rays(cam)
+    for kernel in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        rec = W.draw(cam, shadow=True, kernel=kernel)
+        n = check_records(rec, origins, dirs, chunks, True, 0, what=f"c5 kernel {kernel}")
+        assert n > 300000, n
+    W.destroy()
