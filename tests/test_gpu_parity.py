@@ -209,6 +209,55 @@ def test_world_update_after_edits(svo, oracle):
     W.destroy()
 
 
+def test_world_update_patches_its_host_copy_and_takes_a_bad_patch_back(svo, oracle):
+    """svo_world_update without `realloc` patches the library's host copy over the dirty ranges (plus what was appended) instead of
+    copying the chunk: after a sequence of such updates svo_world_chunk returns the caller's pools word for word; an update whose dirty
+    range carries a malformed node is refused and leaves both copies - host and HBM - as they were; the next good update goes through."""
+    import ctypes as C
+    O = oracle.OracleWorld.generate(1, 1, 1, 128, 7)
+    W = svo.World.create([O.chunk(0)], 1, 1, 1, 128)
+    W.upload(0)
+    rng = np.random.default_rng(5)
+    o, d = random_rays(rng, 6000, (0, 0, 0), (128, 128, 128))
+    patched = 0
+    for k in range(12):
+        lo = rng.uniform(5, 100, 3); hi = lo + rng.uniform(0.5, 25, 3)
+        dt, dw = oracle.Delta(), oracle.Delta()
+        root = C.byref(O.w.chunk[0])
+        if k % 3 == 2:
+            oracle.lib.orc_destroy(root, oracle.vec3(lo), oracle.vec3(hi), C.byref(dt), C.byref(dw))
+        else:
+            oracle.lib.orc_build(root, oracle.vec3(lo), oracle.vec3(hi), 3 + k % 4, C.byref(dt), C.byref(dw))
+        c = O.chunk(0)
+        realloc = bool(dt.realloc_ or dw.realloc_)
+        patched += not realloc
+        W.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right), realloc=realloc)
+        mine = W.chunk(0)
+        assert np.array_equal(mine["tree"], c["tree"]) and np.array_equal(mine["twig"], c["twig"]), f"host copy after update {k}"
+    assert patched >= 6
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    for kern in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+        assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=kern), want, f"after patched updates/{kern}")
+    # a malformed node inside the dirty range: refused, nothing changes
+    good = O.chunk(0)
+    bad = dict(good); bad["tree"] = good["tree"].copy()
+    victim = int(np.nonzero((bad["tree"] >> 30) == 2)[0][-1])                   # the last BRANCH: send it past the pool
+    bad["tree"][victim] = (2 << 30) | (bad["tree"].size + 8)
+    with pytest.raises(svo.SvoError) as e:
+        W.update(0, bad, tree_range=(victim, victim + 1), twig_range=(0, 0))
+    assert e.value.code == -4
+    mine = W.chunk(0)
+    assert np.array_equal(mine["tree"], good["tree"]) and np.array_equal(mine["twig"], good["twig"]), "a refused patch is taken back"
+    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_STACK), want, "after the refused update")
+    dt, dw = oracle.Delta(), oracle.Delta()
+    oracle.lib.orc_build(C.byref(O.w.chunk[0]), oracle.vec3((60, 100, 60)), oracle.vec3((64, 104, 64)), 6, C.byref(dt), C.byref(dw))
+    c = O.chunk(0)
+    W.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right), realloc=bool(dt.realloc_ or dw.realloc_))
+    want = O.trace_rays(o, d, params=oracle.make_params(shadow=True), threads=8)
+    assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=svo.KERNEL_STACK), want, "the next good update")
+    W.destroy()
+
+
 # (a wide-tree rebuild that fails - fault injection - behind svo_world_update / edit_box / shift: tests/test_variants.py, `hooks`;
 # the shipped library no longer reads the injection variable)
 
