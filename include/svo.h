@@ -280,7 +280,10 @@ int svo_world_upload(svo_world *, int device);
 
 /* Replace chunk `chunk` by `desc` (edited pools) and refresh HBM: ranges [tree_left,tree_right)
  * nodes and [twig_left,twig_right) bricks are re-sent in place; realloc!=0 (or growth beyond the
- * chunk's slot) re-packs the chunk at the pool tail == Ocdelta semantics, src/Octree.h:47-54. */
+ * chunk's slot) re-packs the chunk at the pool tail == Ocdelta semantics, src/Octree.h:47-54.
+ * As with the reference's glBufferSubData, with realloc == 0 only the ranges (and whatever desc holds beyond the chunk's previous
+ * length) are taken from desc - the library's own host copy and HBM keep the rest - so they must cover every word that changed;
+ * the result is validated as a whole and a malformed one is refused with nothing changed (SVO_ERR_MALFORMED_TREE). */
 int svo_world_update(svo_world *, int chunk, const svo_chunk_desc *desc,
                      uint64_t tree_left, uint64_t tree_right,
                      uint64_t twig_left, uint64_t twig_right, int realloc);
