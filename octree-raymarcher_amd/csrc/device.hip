@@ -907,7 +907,7 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     }
     if (want == SVO_KERNEL_POOL) {
 #ifndef SVO_WITH_POOL
-        set_error("svo_trace: SVO_KERNEL_POOL is an experiment of round 4 (DESIGN.md §6) that only builds with -DSVO_WITH_POOL carry");
+        set_error("svo_trace: SVO_KERNEL_POOL is an experiment of round 4 (DESIGN.md §6) that only builds with -DSVO_WITH_POOL (the `pool` variant of the Makefile) carry");
         return SVO_ERR_UNSUPPORTED;
 #endif
         if (!stack_ok || !pool_ok(w, A)) { set_error("svo_trace: SVO_KERNEL_POOL (experimental) needs what SVO_KERNEL_STACK needs, CPU semantics, <= 64 chunks of depth <= 12 and no tile cost / order"); return SVO_ERR_UNSUPPORTED; }
