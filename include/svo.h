@@ -143,13 +143,9 @@ typedef struct svo_camera {
 enum {                              /* svo_trace_params.kernel */
     SVO_KERNEL_AUTO    = 0,         /* fastest kernel valid for this world */
     SVO_KERNEL_LITERAL = 1,         /* one thread per ray, restart-from-root, any geometry */
-    SVO_KERNEL_STACK   = 2,         /* persistent waves, LDS descent stack, ballot refill: exact geometry, chunk depth <= 24
+    SVO_KERNEL_STACK   = 2          /* persistent waves, LDS descent stack, ballot refill: exact geometry, chunk depth <= 24
                                        (chunks of one world may differ in depth); worlds beyond 4 GiB of wide nodes get its
                                        large-world instantiation; SVO_ERR_UNSUPPORTED otherwise (AUTO falls back to LITERAL) */
-    SVO_KERNEL_POOL    = 3          /* an EXPERIMENT of round 4, compiled only into builds made with -DSVO_WITH_POOL (scripts/pool_check.py):
-                                       the stack kernel over-subscribed - workgroups of four waves share ray queues in LDS, waiting rays leave
-                                       their lanes, chunk steps and hit resolves run on 64 parked rays at a time.  Same records, slower.  The
-                                       shipped library answers SVO_ERR_UNSUPPORTED; never picked by AUTO */
 };
 
 typedef struct svo_trace_params {

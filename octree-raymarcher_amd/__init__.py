@@ -44,7 +44,7 @@ OK_LITERAL_ONLY = 1     # svo_world_update / edit_box / shift: applied, but the 
 ERR_NAMES = {0: "SVO_OK", -1: "SVO_ERR_INVALID_ARG", -2: "SVO_ERR_NO_DEVICE", -3: "SVO_ERR_OUT_OF_MEMORY",
              -4: "SVO_ERR_MALFORMED_TREE", -5: "SVO_ERR_NOT_UPLOADED", -6: "SVO_ERR_UNSUPPORTED", -7: "SVO_ERR_HIP"}
 EMPTY, LEAF, BRANCH, TWIG = 0, 1, 2, 3
-KERNEL_AUTO, KERNEL_LITERAL, KERNEL_STACK, KERNEL_POOL = 0, 1, 2, 3     # (POOL: experimental over-subscribed stack kernel)
+KERNEL_AUTO, KERNEL_LITERAL, KERNEL_STACK = 0, 1, 2
 EDIT_BUILD, EDIT_DESTROY, EDIT_REPLACE = 0, 1, 2     # svo_world_edit_box
 HIT_FLAG, SHADOW_TRACED, SHADOWED, FACE_NORMAL, ERR_FLAG = 1, 2, 4, 8, 1 << 15
 NORMAL_CUBE, NORMAL_FACE = 0, 1

@@ -31,9 +31,6 @@
 
 #include "kernel_literal.hip.h"
 #include "kernel_stack.hip.h"
-#ifdef SVO_WITH_POOL
-#include "kernel_pool.hip.h"     // the over-subscribed experiment of round 4: not in the shipped library
-#endif
 #include "wide_tree.hip.h"
 #include "world.h"
 
@@ -213,27 +210,6 @@ static int launch_stack(svo_world *w, const TraceArgs &A, int tiles_per_wave, in
     return A.glsl ? launch_stack_as<MAXLV, BIG, true>(w, A, tiles_per_wave, in_flight, s) : launch_stack_as<MAXLV, BIG, false>(w, A, tiles_per_wave, in_flight, s);
 }
 
-#ifdef SVO_WITH_POOL
-// The over-subscribed kernel: workgroups of POOL_WAVES waves; as many as the device keeps resident, never more than the tiles ask for.
-template <int MAXLV>
-static int launch_pool(svo_world *w, const TraceArgs &A, int tiles_per_wave, int in_flight, hipStream_t s)
-{
-    auto kernel = k_trace_pool<MAXLV, SVO_POOL_WAVES_PER_SIMD>;
-    if (w->pool_blocks <= 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, w->device) != hipSuccess) return SVO_ERR_HIP;
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * POOL_WAVES, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-        w->pool_blocks = prop.multiProcessorCount * per_cu;
-    }
-    const int64_t per_group = (int64_t)POOL_WAVES * (tiles_per_wave > 1 ? tiles_per_wave : 1);
-    const int64_t tiles = (int64_t)A.ntiles * (A.nframes > 0 ? A.nframes : 1);
-    const int64_t slots = in_flight >= 2 ? std::max<int64_t>(1, (int64_t)w->pool_blocks * 2 / in_flight) : w->pool_blocks;
-    const int blocks = (int)std::min<int64_t>((tiles + per_group - 1) / per_group, slots);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64 * POOL_WAVES), 0, s, A);
-    return SVO_OK;
-}
-#endif
 
 } // namespace svo
 
@@ -321,7 +297,7 @@ int alloc_pools(svo_world &w, int device)
         hipMemset(w.d_mask, 0, w.twig_pool_cap * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(w.d_bmat, 0, w.twig_pool_cap * sizeof(uint16_t)) != hipSuccess ||
         hipMemset(w.d_work, 0, WORK_SLOTS * WORK_SLOT_WORDS * sizeof(unsigned long long)) != hipSuccess) { set_error("svo_world_upload: hipMemset failed"); return SVO_ERR_HIP; }
-    w.occupancy_blocks = 0; w.pool_blocks = 0;
+    w.occupancy_blocks = 0;
     w.wide_ok = false;                                                  // until build_wide_all has run
     return SVO_OK;
 }
@@ -889,12 +865,6 @@ static bool stack_needs_big(const svo_world *w)
 #endif
 }
 
-// the experimental over-subscribed kernel (kernel_pool.hip.h) marches what its first version covers
-static bool pool_ok(const svo_world *w, const TraceArgs &A)
-{
-    return !A.glsl && !A.tile_cost && !A.tile_order && w->width * w->height * w->depth <= 64 && w->max_levels <= 10 && !stack_needs_big(w);
-}
-
 static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const TraceArgs &A)
 {
     const int want = prm ? prm->kernel : SVO_KERNEL_AUTO;
@@ -904,14 +874,6 @@ static int pick_kernel(const svo_world *w, const svo_trace_params *prm, const Tr
     if (want == SVO_KERNEL_STACK) {
         if (!stack_ok) { set_error("svo_trace: SVO_KERNEL_STACK needs exact geometry, chunk depth <= 24 and the world's wide trees (svo_world_info.wide_nodes)"); return SVO_ERR_UNSUPPORTED; }
         return SVO_KERNEL_STACK;
-    }
-    if (want == SVO_KERNEL_POOL) {
-#ifndef SVO_WITH_POOL
-        set_error("svo_trace: SVO_KERNEL_POOL is an experiment of round 4 (DESIGN.md §6) that only builds with -DSVO_WITH_POOL (the `pool` variant of the Makefile) carry");
-        return SVO_ERR_UNSUPPORTED;
-#endif
-        if (!stack_ok || !pool_ok(w, A)) { set_error("svo_trace: SVO_KERNEL_POOL (experimental) needs what SVO_KERNEL_STACK needs, CPU semantics, <= 64 chunks of depth <= 12 and no tile cost / order"); return SVO_ERR_UNSUPPORTED; }
-        return SVO_KERNEL_POOL;
     }
     if (want != SVO_KERNEL_AUTO) { set_error("svo_trace: unknown kernel id"); return SVO_ERR_INVALID_ARG; }
     return (stack_ok && !A.counters) ? SVO_KERNEL_STACK : SVO_KERNEL_LITERAL;
@@ -937,13 +899,6 @@ static int launch(svo_world *w, const svo_trace_params *prm, TraceArgs &A, hipSt
         const int64_t blocks = (A.n + 255) / 256;
         if (blocks > 0x7FFFFFFF) { set_error("svo_trace: too many rays for one launch"); return SVO_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(k_trace_literal, dim3((unsigned)blocks), dim3(256), 0, s, A);
-#ifdef SVO_WITH_POOL
-    } else if (kernel == SVO_KERNEL_POOL) {
-        if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
-        const int tpw = prm ? prm->tiles_per_wave : 0, nfl = prm ? prm->launches_in_flight : 0;
-        const int rc = w->max_levels <= 6 ? launch_pool<6>(w, A, tpw, nfl, s) : launch_pool<10>(w, A, tpw, nfl, s);
-        if (rc != SVO_OK) { set_error("svo_trace: device query failed"); return rc; }
-#endif
     } else {
         if (A.ntiles > (1 << 25)) { set_error("svo_trace: more than 2^31 rays in one stack-kernel launch"); return SVO_ERR_UNSUPPORTED; }
         if (A.tile_cost) HIP_TRY(hipMemsetAsync(A.tile_cost, 0, (size_t)A.ntiles * (size_t)(A.from_camera ? A.nframes : 1) * 2 * sizeof(uint32_t), s));

@@ -46,7 +46,7 @@
 //  * Instantiations (round 4): BIG - 64-bit wide-tree and mask addresses for worlds beyond 4 GiB of wide nodes / 2^29 bricks, a
 //    128-chunk LDS table; GLSL - the march of shaders/Chunkmarch.glsl (svo_trace_params.semantics): guarded escape distance, LEAF
 //    hits at t, tnear > 0 at the world entry, no containment re-check.  The asm statement (step_asm_body.inc) and the creep block
-//    (creep_block.inc) are shared text; kernel_pool.hip.h is the over-subscribed experiment built on the same pieces.
+//    (creep_block.inc) are shared text.
 //
 // All float arithmetic that decides t is evaluated exactly as in the reference; only loads and
 // integer bookkeeping differ.  Divisions by powers of two (chunk edge, node edge) are written as

@@ -46,7 +46,6 @@ struct svo_world {
     uint64_t tree_pool_len = 0, twig_pool_len = 0;    // elements in use (incl. alignment padding)
     uint64_t tree_pool_cap = 0, twig_pool_cap = 0;    // elements allocated
     int occupancy_blocks = 0;                     // cached persistent-grid size
-    int pool_blocks = 0;                          // ... of the over-subscribed kernel (workgroups of four waves)
 };
 
 namespace svo {

@@ -1,7 +1,7 @@
 """The variant builds of the library (octree-raymarcher_amd/Makefile `variants`, built by __graft_entry__.build()) must not rot
 unseen: the C++ march step that kernel_stack.hip.h calls the readable statement of the algorithm, the timing
-build whose lane counters DESIGN.md quotes, the large-pool kernel forced onto small worlds, the test hooks the shipped library
-no longer reads, and the over-subscribed kernel experiment whose counters DESIGN.md §6 records.  Each runs in its own process (one library per process), one after the other."""
+build whose lane counters DESIGN.md quotes, the large-pool kernel forced onto small worlds, and the test hooks the shipped library
+no longer reads.  Each runs in its own process (one library per process), one after the other."""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "octree-raymarcher_amd", "build")
 CHECK = os.path.join(ROOT, "tests", "variant_check.py")
-VARIANTS = [("cxxstep", "march"), ("wide64", "march"), ("timing", "march"), ("timing", "timing"), ("hooks", "hooks"), ("pool", "pool")]
+VARIANTS = [("cxxstep", "march"), ("wide64", "march"), ("timing", "march"), ("timing", "timing"), ("hooks", "hooks")]
 
 
 def lib_of(name):

@@ -6,7 +6,6 @@ one after the other.
     python tests/variant_check.py <path to libsvo_*.so> march          goldens + the C1 image + adversarial / creeping rays + a world of mixed depths
     python tests/variant_check.py <path to libsvo_hooks.so> hooks      failed wide-tree rebuilds (SVO_TEST_FAIL_WIDE) behind update, edit and shift
     python tests/variant_check.py <path to libsvo_timing.so> timing    the timing build's counters are there and consistent with the records
-    python tests/variant_check.py <path to libsvo_pool.so> pool        SVO_KERNEL_POOL (round 4's over-subscribed experiment) against the oracle and the stack kernel
 
 exit 0 = every check passed; anything else fails the test with this script's output.
 """
@@ -199,38 +198,6 @@ def hooks(svo, ob):
     print("hooks: failed wide rebuilds behind update / edit_box / shift leave the change applied and the literal kernel marching; the next one recovers")
 
 
-def pool(svo, ob):
-    """-DSVO_WITH_POOL: the over-subscribed kernel of round 4 (csrc/kernel_pool.hip.h; measured and not adopted) still equals
-    the oracle - ray lists with and without shadow rays, a frame in both normal modes, three frames per launch - and the stack kernel."""
-    from helpers import adversarial_rays, assert_gbuffer_equal, creeping_rays, random_rays
-    ccm = (-1, 0, -1)
-    W = svo.World.generate(2, 1, 2, 128, 8, chunkcoordmin=ccm)
-    O = ob.OracleWorld.from_chunks([W.chunk(i) for i in range(4)], 2, 1, 2, 128, ccm)
-    W.upload(0)
-    lo, hi = (-128.0, 0.0, -128.0), (128.0, 128.0, 128.0)
-    rng = np.random.default_rng(7)
-    for name, (o, d) in {"tiny": random_rays(rng, 100, lo, hi), "random": random_rays(rng, 40000, lo, hi), "adversarial": adversarial_rays(rng, 30000, lo, hi),
-                         "creeping": creeping_rays(rng, 4000, lo, hi, 0.5)}.items():
-        for shadow in (False, True):
-            want = O.trace_rays(o, d, params=ob.make_params(shadow=shadow), threads=8)
-            assert_gbuffer_equal(W.chunkmarch(o, d, shadow=shadow, kernel=svo.KERNEL_POOL), want, f"pool {name} shadow={shadow}")
-            assert W.last_ray_count() == O.last_rays, (name, W.last_ray_count(), O.last_rays)
-    cam = svo.make_camera((0.3, 150.0, -170.2), (0.0, -0.5, 0.866), (0, 1, 0), 60.0, 640, 360)
-    for nm in (0, 1):
-        want = O.trace_image(cam, params=ob.make_params(shadow=True, normal_mode=nm), threads=8)
-        assert_gbuffer_equal(W.draw(cam, shadow=True, kernel=svo.KERNEL_POOL, normal_mode=nm), want, f"pool frame normal mode {nm}")
-    out = svo.DeviceBuffer(3 * 640 * 360 * 32)
-    W.trace_frames([cam] * 3, svo.trace_params(shadow=True, kernel=svo.KERNEL_POOL), (0, 0, 640, 360), out.ptr)
-    svo.lib.svo_stream_synchronize(None)
-    want = O.trace_image(cam, params=ob.make_params(shadow=True), threads=8)
-    three = out.to_numpy(svo.HIT_DTYPE, 3 * 640 * 360).reshape(3, 360, 640)
-    for f in range(3):
-        assert_gbuffer_equal(three[f], want, f"pool frame {f} of 3")
-    assert W.draw(cam, shadow=True, kernel=svo.KERNEL_STACK).tobytes() == W.draw(cam, shadow=True, kernel=svo.KERNEL_POOL).tobytes()
-    W.destroy()
-    print("pool: SVO_KERNEL_POOL equals the oracle on ray lists (random / adversarial / creeping, with and without shadow rays) and frames, and the stack kernel byte for byte")
-
-
 def timing(svo, ob):
     """-DSVO_STACK_TIMING: six uint4 per wave through counters_dev (kernel_stack.hip.h, end of the kernel)."""
     from helpers import assert_gbuffer_equal
@@ -265,4 +232,4 @@ if __name__ == "__main__":
     svo, ob = load(lib_path)
     if svo.device_count() < 1:
         print("no HIP device"); sys.exit(3)
-    {"march": march, "hooks": hooks, "timing": timing, "pool": pool}[what](svo, ob)
+    {"march": march, "hooks": hooks, "timing": timing}[what](svo, ob)
