@@ -53,3 +53,57 @@ def test_fill_word_keeps_child_block_indices_up_to_the_frontier_limit():
     exe = compile_host("format_check.cpp", extra=["-I../csrc"])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout
+
+
+def test_world_update_host_copy_patch_and_rollback(svo, oracle):
+    """svo_world_update's host half, no device needed (a world that was never uploaded takes updates too): without `realloc` the
+    library's copy of the chunk is patched over the dirty ranges + the appended tail, and equals the caller's pools after every one
+    of a sequence of oracle edits (Ocdelta ranges, src/Octree.h:47-54); ranges that lie (or a malformed node inside them) are refused
+    by the whole-chunk validation and the copy is restored word for word; a shrunken pool or `realloc` takes the copying path."""
+    import ctypes as C
+    O = oracle.OracleWorld.generate(1, 1, 1, 128, 6)
+    W = svo.World.create([O.chunk(0)], 1, 1, 1, 128)
+    rng = np.random.default_rng(11)
+    kinds = 0
+    for k in range(30):
+        lo = rng.uniform(2, 110, 3); hi = lo + rng.uniform(0.3, 30, 3)
+        dt, dw = oracle.Delta(), oracle.Delta()
+        root = C.byref(O.w.chunk[0])
+        if k % 3 == 1:
+            oracle.lib.orc_destroy(root, oracle.vec3(lo), oracle.vec3(hi), C.byref(dt), C.byref(dw))
+        else:
+            oracle.lib.orc_build(root, oracle.vec3(lo), oracle.vec3(hi), 2 + k % 5, C.byref(dt), C.byref(dw))
+        c = O.chunk(0)
+        realloc = bool(dt.realloc_ or dw.realloc_)
+        kinds |= 2 if realloc else 1
+        assert W.update(0, c, tree_range=(min(dt.left, c["tree"].size), dt.right), twig_range=(min(dw.left, c["twig"].size // 64), dw.right), realloc=realloc) == 0
+        mine = W.chunk(0)
+        assert np.array_equal(mine["tree"], c["tree"]) and np.array_equal(mine["twig"], c["twig"]), f"host copy after update {k} (realloc {realloc})"
+    assert kinds == 3, "the sequence exercised both the patching and the copying path"
+    good = O.chunk(0)
+    # a BRANCH sent past the pool inside the dirty range
+    bad = dict(good); bad["tree"] = good["tree"].copy()
+    victim = int(np.nonzero((bad["tree"] >> 30) == 2)[0][-1])
+    bad["tree"][victim] = (2 << 30) | (bad["tree"].size + 8)
+    with pytest.raises(svo.SvoError) as e:
+        W.update(0, bad, tree_range=(victim, victim + 1), twig_range=(0, 0))
+    assert e.value.code == -4
+    # the root turned into a TWIG that points past the brick pool, in an update that also appends a block (the patch grows the copy first)
+    bad2 = dict(good); bad2["tree"] = np.concatenate([good["tree"], np.zeros(8, np.uint32)])
+    bad2["tree"][0] = (3 << 30) | 0x3FFFFFF
+    with pytest.raises(svo.SvoError):
+        W.update(0, bad2, tree_range=(0, 1), twig_range=(0, 0))
+    mine = W.chunk(0)
+    assert np.array_equal(mine["tree"], good["tree"]) and np.array_equal(mine["twig"], good["twig"]), "refused patches are taken back"
+    # empty and inverted ranges change nothing; ranges past the end are clamped
+    assert W.update(0, good, tree_range=(5, 5), twig_range=(7, 3)) == 0
+    assert W.update(0, good, tree_range=(good["tree"].size + 100, good["tree"].size + 200), twig_range=(10 ** 9, 10 ** 9 + 5)) == 0
+    mine = W.chunk(0)
+    assert np.array_equal(mine["tree"], good["tree"]) and np.array_equal(mine["twig"], good["twig"])
+    # a pool that has shrunk (a re-grown chunk) cannot be patched: the copying path takes it
+    small = oracle.OracleWorld.generate(1, 1, 1, 128, 4).chunk(0)
+    assert small["tree"].size < good["tree"].size
+    assert W.update(0, small, tree_range=(0, 1), twig_range=(0, 0)) == 0
+    mine = W.chunk(0)
+    assert np.array_equal(mine["tree"], small["tree"]) and np.array_equal(mine["twig"], small["twig"]) and mine["depth"] == 4
+    W.destroy()
