@@ -56,6 +56,7 @@ WORKLOADS = {
     "c4_2160p_depth12_4x1x4_shadow": (4, 1, 4, 12, 3840, 2160, True),      # BASELINE configs[3]
     "c5_1080p_depth16_sparse_shadow": (1, 1, 1, 16, 1920, 1080, True),     # BASELINE configs[4]: full depth in a 4-unit band
     "c3_grazing_1080p_depth12_4x1x4_shadow": (4, 1, 4, 12, 1920, 1080, True),   # SURVEY §8d second camera: inside the world, looking along it
+    "ref_default_1080p_depth8_4x4x4_shadow": (4, 4, 4, 8, 1920, 1080, True),    # the reference's own default scene: world.init(4, 4, 4, 128), TREE_MAX_DEPTH 8 (src/Main.cpp:80, src/World.cpp:10)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_STREAM_GBS = 6300.0        # ... and what a streaming copy achieves (6.29 TB/s measured)
@@ -70,7 +71,8 @@ FRAMES_PER_LAUNCH = {1: 8, 2: 16, 4: 16, 8: 16}     # consecutive frames marched
 # throughput of four of eight (6.9 Grays/s either way, 5.9 at 20 steps) and spread a launch's one drain over twice the frames
 # (serialized launch: 0.566 against 0.640 ms per frame).  C2's and C5's frames are short (0.2 - 0.3 ms): they want four launches in
 # flight (C2 with two: 6.5 against 11.1 Grays/s) and lose 2 - 7 % with 16 frames per launch.
-LAUNCH_SHAPE = {"c3_1080p_depth12_4x1x4_shadow": (2, 16), "c4_2160p_depth12_4x1x4_shadow": (2, 16)}
+LAUNCH_SHAPE = {"c3_1080p_depth12_4x1x4_shadow": (2, 16), "c4_2160p_depth12_4x1x4_shadow": (2, 16),
+                "ref_default_1080p_depth8_4x4x4_shadow": (2, 16)}     # (7.9 - 8.4 against 7.1 - 7.3 Grays/s with 4 x 8, gpurun_out/s2_refdefault_shapes.txt)
 PATH_CAMERAS = 32
 
 

@@ -105,6 +105,34 @@ def test_c4_2160p_band_partition_of_8(svo, oracle, c3):
     check_properties(svo, full, True)
 
 
+def test_reference_default_scene(svo, oracle):
+    """The reference's OWN default workload (SURVEY.md §5 "default workload"): `world.init(4, 4, 4, 128)` with TREE_MAX_DEPTH 8 and a
+    256-texel pyramid (src/Main.cpp:80, src/World.cpp:10-11,19-43) at 1920x1080 - 64 chunks of depth 8, every entry of the stack
+    kernel's LDS chunk table in use, a world four chunks high.  Seen (a) from the bench's kind of view, whole frame, and (b) from
+    the reference's start position: the world's corner, eye ON the lattice at (0, 0, 0), looking along +z with a 90 degree field
+    of view (src/Main.cpp:133-139).  Primary + shadow rays, both kernels, the CPU march and its GLSL twin, against the oracle."""
+    W = svo.World.generate(4, 4, 4, 128, 8)
+    assert W.info.exact_geometry == 1
+    O = oracle.OracleWorld.from_chunks([W.chunk(i, copy=False) for i in range(64)], 4, 4, 4, 128)
+    W.upload(0)
+    views = {"bench view": svo.default_camera(4, 4, 128, 1920, 1080),
+             "reference start": svo.make_camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), 90.0, 960, 540),
+             "inside, over the terrain": svo.make_camera((200.3, 70.2, 100.1), (0.3, -0.25, 0.9), (0.0, 1.0, 0.0), 90.0, 960, 540)}
+    hits = 0
+    for name, cam in views.items():
+        for sem in (svo.SEMANTICS_CPU, svo.SEMANTICS_GLSL):
+            want = O.trace_image(cam, params=oracle.make_params(shadow=True, semantics=sem), threads=THREADS)
+            for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+                got = W.draw(cam, shadow=True, kernel=k, semantics=sem)
+                assert_gbuffer_equal(got, want, f"reference default scene/{name}/semantics {sem}/{k}")
+            assert W.last_ray_count() == O.last_rays
+            hits += int((want["flags"] & 1).sum())
+            if sem == svo.SEMANTICS_CPU: check_properties(svo, got, True)
+    assert hits > 500000                                            # the terrain is in the pictures
+    assert W.draw(views["bench view"], shadow=True).tobytes() == W.draw(views["bench view"], shadow=True, kernel=svo.KERNEL_STACK).tobytes()   # AUTO = the stack kernel here
+    W.destroy()
+
+
 def node_levels(tree):
     """Level of every node of a BFS-ordered chunk tree (src/Octree.cpp:98-104,165-173): level l+1 holds the 8 children
     of each BRANCH of level l, in order.  Returns the index of the first node of each level."""
