@@ -97,6 +97,12 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 #ifndef SVO_DRAIN_STEPS
 #define SVO_DRAIN_STEPS 8        // (round 4: 8 instead of 4 - one frame 1.62 - 1.63 ms against 1.655 - 1.659, the serialized 16-frame launch 8.79 against 8.91 - 8.99 ms; 16: the same as 8, 2: as 4)
 #endif
+// when a wave skips the bricks whose march is bound to miss (step_asm_body.inc, "sure"): the test is ~75 instructions for every wave-step
+// in which some lane enters a brick, so a wave of the bulk would pay more than its lanes win; a draining wave's instructions are its
+// critical path and the test runs while the brick's mask is on its way
+#ifndef SVO_SURE_MISS_WHEN
+#define SVO_SURE_MISS_WHEN __builtin_amdgcn_readfirstlane(more ? 0 : 1)
+#endif
 #ifndef SVO_STEP_LANES
 #define SVO_STEP_LANES 8
 #endif
@@ -570,6 +576,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #ifndef SVO_CXX_STEP
         // (step_asm.hip.h) the steps of this pass in one statement: 1 + fixed_steps at first, single steps while the inner repeat lasts
         const int nsteps = pass == 0 ? 1 + fixed_steps : SVO_DRAIN_STEPS;
+        const int sure_miss = SVO_SURE_MISS_WHEN;      // (step_asm_body.inc: bricks whose march is bound to miss are not entered)
 #ifdef SVO_STACK_TIMING
 #define SVO_STEP_STATS_ARG , step_stats
 #else
@@ -577,16 +584,16 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
 #endif
         if constexpr (BIG && GLSL)
             march_steps_asm_big_glsl(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                                     beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+                                     beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps | (sure_miss << 16) SVO_STEP_STATS_ARG);
         else if constexpr (GLSL)
             march_steps_asm_glsl(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                                 beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+                                 beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps | (sure_miss << 16) SVO_STEP_STATS_ARG);
         else if constexpr (BIG)
             march_steps_asm_big(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                                beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+                                beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps | (sure_miss << 16) SVO_STEP_STATS_ARG);
         else
             march_steps_asm(mode, O, Blo, bsize, res, t, cnt, tt_saved, t_miss, it_saved, tw, cw, pux, puy, puz, valid, plev, bmask, creepn,
-                            beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps SVO_STEP_STATS_ARG);
+                            beta, g, clo, alpha, levels, nw_chunk, res_tree, wide_b, twig_off, lds_lane, SU, nsteps | (sure_miss << 16) SVO_STEP_STATS_ARG);
 #undef SVO_STEP_STATS_ARG
         pass += nsteps - 1;
 #else
@@ -802,6 +809,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_trace_stack(TraceArgs A)
         uint4 h2; h2.x = n_wsteps_b; h2.y = n_lsteps_b; h2.z = n_world_wait; h2.w = n_twig_b;
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 4] = h2;
         uint4 h3; h3.x = step_stats.steps; h3.y = step_stats.lanes; h3.z = step_stats.stalls; h3.w = step_stats.chased;
+#ifdef SVO_SURE_STAT_WORD  // (measurement: the last word counts the brick entries skipped as sure misses instead)
+        h3.w = step_stats.sure;
+#endif
         reinterpret_cast<uint4 *>(A.counters)[6 * blockIdx.x + 5] = h3;
     }
 #endif

@@ -54,12 +54,37 @@
 #else
 #define SVO_STAT(text) ""
 #endif
+// (-DSVO_STACK_TIMING -DSVO_SURE_STAT=k: StepStats::sure counts the lanes that reach stage k of the sure-miss test - 1 entering a brick while
+// the wave drains, 2 p(t_miss) provably outside, 3 guard passed, 4 skipped; default 4)
+#ifndef SVO_SURE_STAT
+#define SVO_SURE_STAT 4
+#endif
+#define SVO_SURE_COUNT(k) SVO_SURE_PICK(k, SVO_SURE_STAT)
+#define SVO_SURE_PICK(k, want) SVO_SURE_PICK_(k, want)
+#define SVO_SURE_PICK_(k, want) SVO_SURE_IS_##k##_##want
+#define SVO_SURE_TEXT SVO_STAT("s_bcnt1_i32_b64 %[na], exec\n\t" "s_add_u32 %[st_sure], %[st_sure], %[na]\n\t")
+#define SVO_SURE_IS_1_1 SVO_SURE_TEXT
+#define SVO_SURE_IS_2_2 SVO_SURE_TEXT
+#define SVO_SURE_IS_3_3 SVO_SURE_TEXT
+#define SVO_SURE_IS_4_4 SVO_SURE_TEXT
+#define SVO_SURE_IS_1_2 ""
+#define SVO_SURE_IS_1_3 ""
+#define SVO_SURE_IS_1_4 ""
+#define SVO_SURE_IS_2_1 ""
+#define SVO_SURE_IS_2_3 ""
+#define SVO_SURE_IS_2_4 ""
+#define SVO_SURE_IS_3_1 ""
+#define SVO_SURE_IS_3_2 ""
+#define SVO_SURE_IS_3_4 ""
+#define SVO_SURE_IS_4_1 ""
+#define SVO_SURE_IS_4_2 ""
+#define SVO_SURE_IS_4_3 ""
 #define SVO_STR_(x) #x
 #define SVO_STR(x) SVO_STR_(x)
 
 namespace svo {
 
-struct StepStats { unsigned steps = 0, lanes = 0, stalls = 0, chased = 0; };    // (-DSVO_STACK_TIMING) wave-steps, marching lanes summed over them, lanes that sat a BRANCH out, lanes that took a level inside the step
+struct StepStats { unsigned steps = 0, lanes = 0, stalls = 0, chased = 0, sure = 0; };    // (-DSVO_STACK_TIMING) wave-steps, marching lanes summed over them, lanes that sat a BRANCH out, lanes that took a level inside the step
 
 struct StepUniform {            // wave-uniform inputs (SGPRs)
     float csize, eps, eps2;
@@ -79,9 +104,11 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
 #define SVO_STEP_ADDR32_ENTRY "v_lshl_add_u32 %[q1], %[q1], 2, %[wb]\n\t" "global_load_dword %[w], %[q1], %[wide]\n\t"
 #define SVO_STEP_ADDR32_MASKOFF "v_lshlrev_b32 %[q6], 3, %[q6]\n\t" "s_nop 0\n\t"
 #define SVO_STEP_ADDR32_MASK "global_load_dwordx2 %[bm], %[q6], %[maskp]\n\t"
+#define SVO_STEP_ADDR32_MASK_HALVES "global_load_dword %[r3], %[q6], %[maskp]\n\t" "global_load_dword %[w], %[q6], %[maskp] offset:4\n\t"
 #define SVO_STEP_ADDR64_ENTRY "v_mad_u64_u32 %[q64], vcc, %[q1], 4, %[wb]\n\t" "global_load_dword %[w], %[q64], off\n\t"
 #define SVO_STEP_ADDR64_MASKOFF "s_nop 1\n\t"
 #define SVO_STEP_ADDR64_MASK "v_mad_u64_u32 %[q64], vcc, %[q6], 8, %[maskp]\n\t" "global_load_dwordx2 %[bm], %[q64], off\n\t"
+#define SVO_STEP_ADDR64_MASK_HALVES "global_load_dword %[r3], %[q64], off\n\t" "global_load_dword %[w], %[q64], off offset:4\n\t"
 #define SVO_STEP_CPU_LEAF "v_subrev_f32 %[q1], %[eps], %[t]\n\t"
 #define SVO_STEP_CPU_GUARD ""
 #define SVO_STEP_GLSL_LEAF "v_mov_b32 %[q1], %[t]\n\t"
@@ -92,6 +119,7 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
 #define SVO_STEP_LOAD_ENTRY SVO_STEP_ADDR32_ENTRY
 #define SVO_STEP_MASK_OFFSET SVO_STEP_ADDR32_MASKOFF
 #define SVO_STEP_LOAD_MASK SVO_STEP_ADDR32_MASK
+#define SVO_STEP_LOAD_MASK_HALVES SVO_STEP_ADDR32_MASK_HALVES
 #define SVO_STEP_LEAF_DISTANCE SVO_STEP_CPU_LEAF
 #define SVO_STEP_ESCAPE_GUARD SVO_STEP_CPU_GUARD
 #include "step_asm_body.inc"
@@ -107,11 +135,13 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
 #undef SVO_STEP_LOAD_ENTRY
 #undef SVO_STEP_MASK_OFFSET
 #undef SVO_STEP_LOAD_MASK
+#undef SVO_STEP_LOAD_MASK_HALVES
 #define SVO_STEP_FN march_steps_asm_big_glsl
 #define SVO_STEP_WIDE_T unsigned long long
 #define SVO_STEP_LOAD_ENTRY SVO_STEP_ADDR64_ENTRY
 #define SVO_STEP_MASK_OFFSET SVO_STEP_ADDR64_MASKOFF
 #define SVO_STEP_LOAD_MASK SVO_STEP_ADDR64_MASK
+#define SVO_STEP_LOAD_MASK_HALVES SVO_STEP_ADDR64_MASK_HALVES
 #include "step_asm_body.inc"
 #undef SVO_STEP_FN
 #undef SVO_STEP_LEAF_DISTANCE
@@ -125,6 +155,7 @@ struct StepUniform {            // wave-uniform inputs (SGPRs)
 #undef SVO_STEP_LOAD_ENTRY
 #undef SVO_STEP_MASK_OFFSET
 #undef SVO_STEP_LOAD_MASK
+#undef SVO_STEP_LOAD_MASK_HALVES
 #undef SVO_STEP_LEAF_DISTANCE
 #undef SVO_STEP_ESCAPE_GUARD
 

@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "octree-raymarcher_amd", "build")
 CHECK = os.path.join(ROOT, "tests", "variant_check.py")
-VARIANTS = [("cxxstep", "march"), ("wide64", "march"), ("timing", "march"), ("timing", "timing"), ("hooks", "hooks")]
+VARIANTS = [("cxxstep", "march"), ("wide64", "march"), ("timing", "march"), ("timing", "timing"), ("hooks", "hooks"),
+            ("suremiss", "march"), ("suremiss64", "march")]      # (the sure-miss brick test in every wave-step, both addressing variants)
 
 
 def lib_of(name):
