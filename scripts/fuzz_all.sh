@@ -4,7 +4,10 @@ timeout -k 10 400 python scripts/fuzz_parity.py 101 300000 0 > gpurun_out/fuzz_a
 timeout -k 10 400 python scripts/fuzz_parity.py 102 300000 1 > gpurun_out/fuzz_b.log 2>&1 && tail -1 gpurun_out/fuzz_b.log
 SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_wide64.so timeout -k 10 400 python scripts/fuzz_parity.py 103 300000 0 > gpurun_out/fuzz_c.log 2>&1 && tail -1 gpurun_out/fuzz_c.log
 SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_wide64.so timeout -k 10 400 python scripts/fuzz_parity.py 104 300000 1 > gpurun_out/fuzz_d.log 2>&1 && tail -1 gpurun_out/fuzz_d.log
-SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_suremiss.so timeout -k 10 400 python scripts/fuzz_parity.py 105 300000 0 > gpurun_out/fuzz_e.log 2>&1 && tail -1 gpurun_out/fuzz_e.log
+SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_suremiss.so timeout -k 10 400 python scripts/fuzz_parity.py 108 300000 0 > gpurun_out/fuzz_e.log 2>&1 && tail -1 gpurun_out/fuzz_e.log
 SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_suremiss.so timeout -k 10 400 python scripts/fuzz_parity.py 106 300000 1 > gpurun_out/fuzz_f.log 2>&1 && tail -1 gpurun_out/fuzz_f.log
 SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_suremiss64.so timeout -k 10 400 python scripts/fuzz_parity.py 107 300000 1 > gpurun_out/fuzz_g.log 2>&1 && tail -1 gpurun_out/fuzz_g.log
+SVO_AMD_LIB=$R/octree-raymarcher_amd/build/libsvo_suremiss64.so timeout -k 10 400 python scripts/fuzz_parity.py 109 300000 0 > gpurun_out/fuzz_h.log 2>&1 && tail -1 gpurun_out/fuzz_h.log
+# (seed 105, CPU semantics, holds a ray of 63 M reference steps - 1000 chunk steps x 1000 tree steps on a chunk face - that every build of both kernels
+#  gives up on with SVO_ERR_FLAG, the shipped library included: scripts/fuzz_one.py 105 300000 0 2 143822)
 timeout -k 10 300 python scripts/eps_check.py > gpurun_out/eps_check.log 2>&1 && tail -2 gpurun_out/eps_check.log
