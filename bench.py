@@ -692,7 +692,8 @@ def run(args):
                     "wave_wait_fraction": iss["wave_wait_fraction"], "wave_active_fraction": iss["wave_active_fraction"], "lane_utilisation_valu": iss["lane_utilisation_valu"],
                     "source": prof.get("source", "") + " (replayed)",
                     "note": "issue_utilisation_profiled_launch is a MODEL (PMC instruction counts x the asm step's static mix priced by scripts/microbench/valu_issue); "
-                            "issue_utilisation_direct_range = the same counts priced between the cheapest class and the weighted mix: quote the range (DESIGN.md §5)"}
+                            "issue_utilisation_direct_range = the same counts priced between the cheapest class and the weighted mix: quote the range (DESIGN.md §5); "
+                            "the prices come from one-class instruction streams and bound a mixed stream from above, so a model figure above 1 reads as: issue slots full"}
             if not args.no_cpu_baseline:
                 ob = importlib.import_module("oracle_binding")      # the oracle: checker/baseline only
                 n = gw * gh * gd

@@ -28,6 +28,7 @@ def cost(op, w, idx=1):
         if r["op"] == op and r["waves_per_simd"] == w and r["exec"] == "all 64 lanes": return r["cycles_per_inst_per_simd_grouped_p10_median_p90"][idx]
 src = open(os.path.join(ROOT, "octree-raymarcher_amd", "csrc", "step_asm_body.inc")).read()
 body = src[src.index("asm volatile("):src.index(': [md] "+v"(mode)')]
+body = body[:body.index('"s_cbranch_scc0 60f')] + '"s_cbranch_scc0 x\\n"\n' + body[body.index('"60:'):]      # (the sure-miss test of draining waves is not part of a bulk step's mix)
 body = body.replace("SVO_STEP_LOAD_ENTRY", '"v_lshl_add_u32 x\\n" "global_load_dword x\\n"').replace("SVO_STEP_MASK_OFFSET", '"v_lshlrev_b32 x\\n" "s_nop 0\\n"') \
            .replace("SVO_STEP_LOAD_MASK", '"global_load_dwordx2 x\\n"').replace("SVO_STEP_LEAF_DISTANCE", '"v_subrev_f32 x\\n"').replace("SVO_STEP_ESCAPE_GUARD", "")     # the default variant's fragments (step_asm.hip.h)
 ins = [i for i in re.findall(r'"\s*([a-z_0-9]+)[ \\]', body) if not i[0].isdigit()]
@@ -66,6 +67,8 @@ issue = {"instructions_per_launch_of_%d_frames" % FPL: insts, "instructions_per_
          "wave_wait_inst_fraction": round(med("prof_pmcA2", "SQ_WAIT_INST_ANY") / med("prof_pmcA1", "SQ_WAVE_CYCLES"), 4),
          "wave_active_fraction": round(med("prof_pmcA1", "SQ_ACTIVE_INST_ANY") / med("prof_pmcA1", "SQ_WAVE_CYCLES"), 4),
          "lane_utilisation_valu": round(med("prof_pmcA2", "SQ_THREAD_CYCLES_VALU") / (64 * med("prof_pmcA2", "SQ_ACTIVE_INST_VALU")), 4),
+         "note_model_above_one": "the prices are measured on streams of ONE instruction class at six waves; in a mixed stream a scalar instruction of one wave issues beside a vector "
+                                 "instruction of another, so the weighted price is an upper bound and a figure above 1 reads as: the SIMDs' issue slots are full",
          "how": "instructions of one serialized 16-frame launch (PMC pass A) / 1024 SIMDs x cycles per instruction, weighted with the static mix of the "
                 "hand-written step (step_asm.hip.h) from scripts/microbench/valu_issue at 6 waves per SIMD (waves grouped by the SIMD they ran on, each "
                 "SIMD's busy interval at the shader clock measured in the same run) / GFX-busy cycles of the launch (GRBM_GUI_ACTIVE / 8 XCCs)"}
