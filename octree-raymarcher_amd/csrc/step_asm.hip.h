@@ -55,7 +55,7 @@
 #define SVO_STAT(text) ""
 #endif
 // (-DSVO_STACK_TIMING -DSVO_SURE_STAT=k: StepStats::sure counts the lanes that reach stage k of the sure-miss test - 1 entering a brick while
-// the wave drains, 2 p(t_miss) provably outside, 3 guard passed, 4 skipped; default 4)
+// the wave drains, 2 p(t_miss) provably outside, 3 guard passed, 4 skipped; of a draining wave: 5 lanes that leave a brick whose march missed, 6 lanes that hit a cell; default 4)
 #ifndef SVO_SURE_STAT
 #define SVO_SURE_STAT 4
 #endif
@@ -63,6 +63,9 @@
 #define SVO_SURE_PICK(k, want) SVO_SURE_PICK_(k, want)
 #define SVO_SURE_PICK_(k, want) SVO_SURE_IS_##k##_##want
 #define SVO_SURE_TEXT SVO_STAT("s_bcnt1_i32_b64 %[na], exec\n\t" "s_add_u32 %[st_sure], %[st_sure], %[na]\n\t")
+#define SVO_SURE_DRAIN_TEXT SVO_STAT("s_bitcmp1_b32 %[nst], 16\n\t" "s_cbranch_scc0 69f\n\t" "s_bcnt1_i32_b64 %[na], exec\n\t" "s_add_u32 %[st_sure], %[st_sure], %[na]\n\t" "69:\n\t")
+#define SVO_SURE_IS_5_5 SVO_SURE_DRAIN_TEXT
+#define SVO_SURE_IS_6_6 SVO_SURE_DRAIN_TEXT
 #define SVO_SURE_IS_1_1 SVO_SURE_TEXT
 #define SVO_SURE_IS_2_2 SVO_SURE_TEXT
 #define SVO_SURE_IS_3_3 SVO_SURE_TEXT
@@ -79,6 +82,24 @@
 #define SVO_SURE_IS_4_1 ""
 #define SVO_SURE_IS_4_2 ""
 #define SVO_SURE_IS_4_3 ""
+#define SVO_SURE_IS_1_5 ""
+#define SVO_SURE_IS_1_6 ""
+#define SVO_SURE_IS_2_5 ""
+#define SVO_SURE_IS_2_6 ""
+#define SVO_SURE_IS_3_5 ""
+#define SVO_SURE_IS_3_6 ""
+#define SVO_SURE_IS_4_5 ""
+#define SVO_SURE_IS_4_6 ""
+#define SVO_SURE_IS_5_1 ""
+#define SVO_SURE_IS_5_2 ""
+#define SVO_SURE_IS_5_3 ""
+#define SVO_SURE_IS_5_4 ""
+#define SVO_SURE_IS_5_6 ""
+#define SVO_SURE_IS_6_1 ""
+#define SVO_SURE_IS_6_2 ""
+#define SVO_SURE_IS_6_3 ""
+#define SVO_SURE_IS_6_4 ""
+#define SVO_SURE_IS_6_5 ""
 #define SVO_STR_(x) #x
 #define SVO_STR(x) SVO_STR_(x)
 
