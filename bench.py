@@ -308,7 +308,12 @@ def run(args):
         G = shape[1] if shape else FRAMES_PER_LAUNCH.get(max(world_size, args.emulate_share, 1), 4)
     G = max(1, min(G, svo.MAX_FRAMES))
     if args.frames_per_launch <= 0 and args.frames_per_gather <= 0:
-        G = max(1, min(G, args.steps // S))     # a short run: fewer frames per launch rather than idle streams
+        # a short run: fewer frames per launch rather than idle streams - except for the whole frame on one GPU once the run is longer than one
+        # launch (the driver's --steps 20: a launch of 16 and one of 4 - 6 158 - 6 258 Mrays/s against 6 050 - 6 183 for two of 10, and the
+        # launch the run is made of is the one the 200-step figure is made of; profiles/r04_driver_shapes_sure_miss.txt).  The roofline leg below
+        # times the launch sizes of the timed region, the short one included.
+        if not (one_gpu_whole_frame and args.steps > G):
+            G = max(1, min(G, args.steps // S))
     if args.kernel == "literal":
         G = 1                                   # the literal kernel is one launch per frame (svo_trace_last_ray_count reports one frame)
     prm.launches_in_flight = S                  # the timed launches share the wave slots (svo_trace_params.launches_in_flight)
@@ -577,20 +582,31 @@ def run(args):
     kernel_ms_avg = kernel_ms_overlapped
     roof_bytes = None
     if not multi and not args.emulate_share:
-        reps = max(5, min(args.steps // G, 2 * P // G if P > 1 else 20))
+        # the launch sizes of the timed region, in its order and proportion (a run that is no multiple of G ends with a shorter launch, whose
+        # drain weighs more: it is timed too, as often as it occurs), repeated until at least five launches are timed
+        sizes = [k for _, _, k in ev]
+        if len(set(sizes)) == 1:
+            reps = max(5, min(args.steps // G, 2 * P // G if P > 1 else 20))
+            sizes = sizes[:1] * reps
+        else:
+            sizes = sizes * max(1, -(-5 // len(sizes)))
+            reps = len(sizes)
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         st0 = streams[0]
         torch.cuda.synchronize()
         roof_bytes = 0
+        first = 0
         with torch.cuda.stream(st0):
-            for j, (a, b) in enumerate(sev):
+            for (a, b), k in zip(sev, sizes):
                 a.record(st0)
-                world.trace_frames(cams_of(j * G, G), prm_alone, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
+                world.trace_frames(cams_of(first, k), prm_alone, (0, 0, iw, ih), bufs[0].data_ptr(), st0.cuda_stream)
                 b.record(st0)
-                roof_bytes += sum(algo_cam[(j * G + f) % P] for f in range(G))
+                roof_bytes += sum(algo_cam[(first + f) % P] for f in range(k))
+                first += k
         st0.synchronize()
         kernel_ms_sum = sum(a.elapsed_time(b) for a, b in sev)
         kernel_ms_avg = kernel_ms_sum / reps
+        roof_sizes = sizes
 
     if rank == 0 and multi and not args.no_gather:
         # de-interleave once (untimed): frame[(k*N + r)*8 + j] = gathered[r][k][j]
@@ -660,7 +676,7 @@ def run(args):
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "frac_of_achievable_6300": round(achieved / HBM_STREAM_GBS, 5),
                 # PMC figures are NOT measured in this run: replayed from the committed profile of the same workload
-                "traffic": traffic * G if traffic else None,
+                "traffic": traffic * sum(roof_sizes) / reps if traffic else None,       # (per launch of the average size timed, like achieved)
                 "traffic_kind": "L2-miss fabric bytes per launch (FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, so an upper bound on HBM bytes)",
                 "traffic_source": prof.get("source", "none") + " (replayed, not measured in this run)",
                 "l2_hit_rate": prof.get("l2_hit_rate"),
@@ -669,7 +685,7 @@ def run(args):
                 # the same bytes over whole-job time: what the overlapped launches deliver together
                 "achieved_throughput": round(algo_total / elapsed / 1e9, 2),
                 "frac_throughput": round(algo_total / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                "algorithmic_bytes_per_launch": int(roof_bytes // reps), "frames_per_launch": G,
+                "algorithmic_bytes_per_launch": int(roof_bytes // reps), "frames_per_launch": G, "launch_sizes_timed": roof_sizes,
                 "bytes_per_ray": round(sum(algo_cam) / sum(rays_cam), 2),
                 "kernel_ms_avg": round(kernel_ms_avg, 5), "kernel_launches_timed": reps,
                 "kernel_ms_avg_with_frames_in_flight": round(kernel_ms_overlapped, 5),
