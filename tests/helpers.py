@@ -68,6 +68,27 @@ def adversarial_rays(rng, n, lo, hi):
     return o.astype(np.float32), d.astype(np.float32)
 
 
+def guard_boundary_rays(rng, n, lo, hi, edge, eps=1.0 / 8192):
+    """Rays around the conditions of the stack kernel's sure-miss brick test (step_asm_body.inc): one direction component at
+    2^-4 .. 2^4 times the guard's threshold edge / (EPS 2^22), exactly 0, a float32 denormal, 1e-30; a third of the origins on or
+    within an ulp-sized step of a brick lattice plane (multiples of `edge`, the planes through 0 of a world with negative
+    coordinates among them), where p - bmin is inexact and a ray sits within EPS of the box it is about to leave."""
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    o = lo + rng.random((n, 3)) * (hi - lo)
+    k = n // 3
+    ax = rng.integers(0, 3, k)
+    plane = np.round(o[np.arange(k), ax] / edge) * edge
+    o[np.arange(k), ax] = plane + rng.choice([0.0, 1e-7, -1e-7, 3e-5, -3e-5, 1e-4, -1e-4], k) * rng.choice([1.0, edge], k)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    c = edge / (eps * 2.0 ** 22)
+    small = np.concatenate([c * 2.0 ** rng.integers(-4, 5, n - 3 * (n // 8)), np.zeros(n // 8), np.full(n // 8, 1e-39), np.full(n // 8, 1e-30)])
+    rng.shuffle(small)
+    d[np.arange(n), rng.integers(0, 3, n)] = small * rng.choice([-1.0, 1.0], n)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
 FUZZ_CASES = [dict(w=2, h=1, d=2, depth=8, ccm=(0, 0, 0)), dict(w=2, h=2, d=2, depth=6, ccm=(-1, -1, -1)),
               dict(w=1, h=1, d=1, depth=11, ccm=(3, 0, -2)), dict(w=3, h=1, d=1, depth=7, ccm=(-2, 0, 5))]
 

@@ -7,7 +7,7 @@ which is what the kernels are built to deliver).
 import numpy as np
 import pytest
 
-from helpers import FUZZ_CASES, adversarial_rays, assert_gbuffer_equal, chunks_of, creeping_rays, random_rays
+from helpers import FUZZ_CASES, adversarial_rays, assert_gbuffer_equal, chunks_of, creeping_rays, guard_boundary_rays, random_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -469,6 +469,30 @@ def test_fuzz_one_million_adversarial_rays(svo, oracle):
             for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
                 got = W.chunkmarch(o, d, shadow=True, kernel=k, light_dir=light)
                 assert_gbuffer_equal(got, want, f"fuzz {c} kernel {k} light {light}")
+        W.destroy()
+
+
+def test_rays_around_the_sure_miss_conditions(svo, oracle):
+    """The stack kernel's draining waves do not enter a brick whose march is bound to miss (step_asm_body.inc; src/Traverse.cpp:99-105
+    resumes the tree level from the brick's entry point whatever twigmarch did).  Its proof has three conditions - p(t_miss) provably
+    outside the node's box, no backward step (|beta_k| EPS 2^22 >= edge, or beta_k = 0), not creeping - and these lists sit on them:
+    direction components around the guard's threshold, exactly 0, denormal; origins on and next to brick lattice planes, the planes
+    through 0 of worlds with negative coordinates among them.  Short lists too: a launch of a few waves is all drain.  Both
+    semantics (tests/test_variants.py runs the same lists with the test forced into every wave-step, variants suremiss / suremiss64)."""
+    for c, n in ((FUZZ_CASES[1], 60000), (FUZZ_CASES[2], 60000), (FUZZ_CASES[3], 3000), (FUZZ_CASES[0], 700)):
+        W = svo.World.generate(c["w"], c["h"], c["d"], 128, c["depth"], chunkcoordmin=c["ccm"])
+        nch = c["w"] * c["h"] * c["d"]
+        O = oracle.OracleWorld.from_chunks([W.chunk(j, copy=False) for j in range(nch)], c["w"], c["h"], c["d"], 128, c["ccm"])
+        W.upload(0)
+        lo = np.array(c["ccm"], float) * 128
+        hi = lo + np.array([c["w"], c["h"], c["d"]]) * 128
+        edge = 4.0 * 128.0 / 2 ** c["depth"]
+        for sem, eps in ((0, 1.0 / 8192), (1, 1.0 / 4096)):
+            o, d = guard_boundary_rays(np.random.default_rng(77 + sem), n, lo, hi, edge, eps)
+            want = O.trace_rays(o, d, params=oracle.make_params(shadow=True, semantics=sem), threads=16)
+            for k in (svo.KERNEL_STACK, svo.KERNEL_LITERAL):
+                got = W.chunkmarch(o, d, shadow=True, kernel=k, semantics=sem)
+                assert_gbuffer_equal(got, want, f"guard {c} semantics {sem} kernel {k}")
         W.destroy()
 
 

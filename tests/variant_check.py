@@ -33,7 +33,7 @@ def load(lib_path):
 
 
 def march(svo, ob):
-    from helpers import adversarial_rays, assert_gbuffer_equal, creeping_rays, random_rays
+    from helpers import adversarial_rays, assert_gbuffer_equal, creeping_rays, guard_boundary_rays, random_rays
     kernels = (svo.KERNEL_STACK, svo.KERNEL_LITERAL)
     # 1. the committed goldens
     for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
@@ -74,7 +74,8 @@ def march(svo, ob):
     lo, hi = (-128, 0, -128), (128, 128, 128)
     rng = np.random.default_rng(404)
     lists = {"random": random_rays(rng, 30000, lo, hi), "adversarial": adversarial_rays(rng, 30000, lo, hi),
-             "creeping": creeping_rays(rng, 4000, lo, hi, 128.0 / 2 ** 7)}
+             "creeping": creeping_rays(rng, 4000, lo, hi, 128.0 / 2 ** 7),
+             "guard": guard_boundary_rays(rng, 24000, lo, hi, 4.0 * 128.0 / 2 ** 7)}        # (around the sure-miss test's conditions; brick edge = 4 voxels)
     for name, (o, d) in lists.items():
         want = O.trace_rays(o, d, params=ob.make_params(shadow=True), threads=8)
         for k in kernels:
@@ -99,7 +100,7 @@ def march(svo, ob):
     for k in kernels:
         assert_gbuffer_equal(W.chunkmarch(o, d, shadow=True, kernel=k), want, f"mixed depths/{k}")
     W.destroy()
-    print("march: goldens, C1 image (both normal modes, 2 frames per launch), random / adversarial / creeping lists (CPU and GLSL semantics), mixed depths: all equal to the oracle")
+    print("march: goldens, C1 image (both normal modes, 2 frames per launch), random / adversarial / creeping / guard-boundary lists (CPU and GLSL semantics), mixed depths: all equal to the oracle")
 
 
 def hooks(svo, ob):
