@@ -97,7 +97,7 @@ enum : int { M_DONE = 0, M_WORLD = 1, M_HIT = 2, M_TREE = 3, M_TWIG = 4 };     /
 #ifndef SVO_DRAIN_STEPS
 #define SVO_DRAIN_STEPS 8        // (round 4: 8 instead of 4 - one frame 1.62 - 1.63 ms against 1.655 - 1.659, the serialized 16-frame launch 8.79 against 8.91 - 8.99 ms; 16: the same as 8, 2: as 4)
 #endif
-// when a wave skips the bricks whose march is bound to miss (step_asm_body.inc, "sure"): the test is ~75 instructions for every wave-step
+// when a wave skips the bricks whose march is bound to miss (step_asm_body.inc, "sure"): the test is ~95 instructions for every wave-step
 // in which some lane enters a brick, so a wave of the bulk would pay more than its lanes win; a draining wave's instructions are its
 // critical path and the test runs while the brick's mask is on its way
 #ifndef SVO_SURE_MISS_WHEN

@@ -24,6 +24,10 @@
 //     where it is loaded but where the NEXT step tests it: behind that step's own descent load (loads return in order),
 //     i.e. for free.
 //
+//   * (round 4) a draining wave - bit 16 of the statement's step count - does not enter a brick whose march is bound to miss: the reference resumes
+//     the tree level from the brick's entry point alone (src/Traverse.cpp:99-105), so a miss proven from the brick's mask needs none of the
+//     brick's steps (step_asm_body.inc, "sure").  Variants suremiss / suremiss64 run the test in every wave-step for the parity tests.
+//
 // Hazards honoured by hand (nothing inside an asm statement is padded by the compiler): v_cmp writing VCC / an SGPR pair
 // -> v_cndmask / v_subbrev reading it: >= 2 instructions in between; every load is waited for inside the statement (the last
 // brick mask at its very end), so that every output is valid when the statement ends.
